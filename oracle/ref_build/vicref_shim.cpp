@@ -1,0 +1,484 @@
+/*
+ * vicref_shim.cpp — TEST INFRASTRUCTURE (never linked into the product).
+ *
+ * A thin extern "C" harness around the *real* reference implementation
+ * (/root/reference, compiled where it lies by oracle/ref_build/build_ref.sh
+ * into oracle/_ref/libvicref*.so).  It converts the flat tables of
+ * include/vicgpu.h into the reference's own structs (cell_info_struct,
+ * soil_con_struct, HRU, atmos_data_struct: vicNl_def.h:900-1539), calls the
+ * reference's initialize_model_state (initialize_model_state.c:8) and
+ * full_energy (full_energy.c:8) exactly as vicNl.c:420-427 / dist_prec.c:159 do,
+ * and converts the result back.  No reference source text lives here: only calls
+ * into it and field-by-field copies.
+ *
+ * Used by tests/ (to pin oracle/vic_oracle.c against the reference and to generate
+ * tests/golden/ fixtures) and by bench.py's cpu_baseline leg (kind "reference").
+ */
+#include "vicNl.h"
+#include "global.h"
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "vicgpu.h"
+
+struct vicref_handle {
+  ProgramState state;
+  vicgpu_options opt;
+  int ncell, nhru, NR, NF;
+  std::vector<cell_info_struct> cells;
+  std::vector<int> hru_cell;          /* global hru id -> cell */
+  std::vector<int> hru_pos;           /* global hru id -> position in the cell's hruList */
+  std::vector<int> cell_off, cell_list;
+  std::vector<double> cp;             /* copy of the cell parameter table */
+  int cp_nrow;
+};
+
+static inline double cpv(const vicref_handle *h, int row, int c) { return h->cp[(size_t)row * h->ncell + c]; }
+
+extern "C" {
+
+void *vicref_create(const vicgpu_options *opt) {
+  if (!opt || opt->abi_version != VICGPU_ABI_VERSION || opt->Nlayer != 3) return NULL;
+  vicref_handle *h = new vicref_handle();
+  h->opt = *opt;
+  ProgramState &s = h->state;
+  s.initialize_global();
+  s.options.Nlayer = opt->Nlayer;
+  s.options.Nnode = opt->Nnode;
+  s.options.SNOW_BAND = opt->Nband;
+  s.options.SNOW_STEP = opt->snow_step;
+  s.options.FULL_ENERGY = opt->FULL_ENERGY;
+  s.options.FROZEN_SOIL = opt->FROZEN_SOIL;
+  s.options.QUICK_FLUX = opt->QUICK_FLUX;
+  s.options.NOFLUX = opt->NOFLUX;
+  s.options.EXP_TRANS = opt->EXP_TRANS;
+  s.options.GRND_FLUX_TYPE = opt->GRND_FLUX_TYPE;
+  s.options.TFALLBACK = opt->TFALLBACK;
+  s.options.AERO_RESIST_CANSNOW = opt->AERO_RESIST_CANSNOW;
+  s.options.SNOW_ALBEDO = opt->SNOW_ALBEDO;
+  s.options.SNOW_DENSITY = opt->SNOW_DENSITY;
+  s.options.TEMP_TH_TYPE = opt->TEMP_TH_TYPE;
+  s.options.GLACIER_ID = opt->GLACIER_ID;
+  s.options.GLACIER_DYNAMICS = opt->GLACIER_DYNAMICS != 0;
+  s.options.CONTINUEONERROR = TRUE;
+  s.global_param.dt = opt->dt;
+  s.global_param.out_dt = opt->dt;
+  s.global_param.wind_h = opt->wind_h;
+  s.global_param.measure_h = 2.0;
+  s.global_param.resolution = 0.0625f;
+  s.global_param.nrecs = 24 / opt->dt * 366 * 100;
+  s.global_param.startyear = 2000; s.global_param.startmonth = 1; s.global_param.startday = 1; s.global_param.starthour = 0;
+  s.global_param.glacierAccumStartYear = 0; s.global_param.glacierAccumStartMonth = 0; s.global_param.glacierAccumStartDay = 0;
+  s.global_param.glacierAccumInterval = 0;
+  s.glacier_accum_started = false;
+  h->NF = VICGPU_NF(opt);
+  h->NR = VICGPU_NR(opt);
+  s.NF = h->NF; s.NR = h->NR;
+  s.dt_sec = opt->dt * 3600; s.out_dt_sec = s.dt_sec; s.out_step_ratio = 1;
+  s.num_veg_types = opt->nveg_types;
+  h->ncell = h->nhru = 0;
+  return h;
+}
+
+void vicref_destroy(void *hv) {
+  vicref_handle *h = (vicref_handle *)hv;
+  if (!h) return;
+  delete h;   /* (small leaks of calloc'ed band arrays / atmos are accepted in this test harness) */
+}
+
+int vicref_set_veglib(void *hv, int nrow, const double *t) {
+  vicref_handle *h = (vicref_handle *)hv;
+  if (nrow != h->opt.nveg_types + 4) return -1;
+  veg_lib_struct *vl = (veg_lib_struct *)calloc(nrow, sizeof(veg_lib_struct));
+  for (int i = 0; i < nrow; i++) {
+    const double *r = t + (size_t)i * VL_NFIELD;
+    vl[i].overstory = (char)(r[VL_OVERSTORY] != 0);
+    vl[i].rarc = r[VL_RARC]; vl[i].rmin = r[VL_RMIN]; vl[i].rad_atten = r[VL_RAD_ATTEN];
+    vl[i].trunk_ratio = r[VL_TRUNK_RATIO]; vl[i].wind_atten = r[VL_WIND_ATTEN]; vl[i].wind_h = r[VL_WIND_H];
+    vl[i].RGL = (float)r[VL_RGL]; vl[i].veg_class = (int)r[VL_VEG_CLASS];
+    vl[i].NVegLibTypes = h->opt.nveg_types;
+    for (int m = 0; m < 12; m++) {
+      vl[i].LAI[m] = r[VL_LAI + m]; vl[i].Wdmax[m] = r[VL_WDMAX + m]; vl[i].albedo[m] = r[VL_ALBEDO + m];
+      vl[i].displacement[m] = r[VL_DISPLACEMENT + m]; vl[i].emissivity[m] = r[VL_EMISSIVITY + m];
+      vl[i].roughness[m] = r[VL_ROUGHNESS + m];
+    }
+  }
+  h->state.veg_lib = vl;
+  return 0;
+}
+
+static void fill_soil_con(vicref_handle *h, int c, soil_con_struct *sc) {
+  const int Nn = h->opt.Nnode, Nb = h->opt.Nband;
+  memset(sc, 0, sizeof(*sc));
+  sc->Ds = cpv(h, CP_DS, c); sc->Dsmax = cpv(h, CP_DSMAX, c); sc->Ws = cpv(h, CP_WS, c); sc->c = cpv(h, CP_C, c);
+  sc->b_infilt = cpv(h, CP_B_INFILT, c); sc->dp = cpv(h, CP_DP, c); sc->avg_temp = cpv(h, CP_AVG_TEMP, c);
+  sc->rough = cpv(h, CP_ROUGH, c); sc->snow_rough = cpv(h, CP_SNOW_ROUGH, c);
+  sc->elevation = (float)cpv(h, CP_ELEVATION, c); sc->lat = (float)cpv(h, CP_LAT, c);
+  sc->FS_ACTIVE = (int)cpv(h, CP_FS_ACTIVE, c);
+  sc->NEW_SNOW_ALB = cpv(h, CP_NEW_SNOW_ALB, c);
+  sc->SNOW_ALB_ACCUM_A = cpv(h, CP_SNOW_ALB_ACCUM_A, c); sc->SNOW_ALB_ACCUM_B = cpv(h, CP_SNOW_ALB_ACCUM_B, c);
+  sc->SNOW_ALB_THAW_A = cpv(h, CP_SNOW_ALB_THAW_A, c); sc->SNOW_ALB_THAW_B = cpv(h, CP_SNOW_ALB_THAW_B, c);
+  sc->MIN_RAIN_TEMP = cpv(h, CP_MIN_RAIN_TEMP, c); sc->MAX_SNOW_TEMP = cpv(h, CP_MAX_SNOW_TEMP, c);
+  sc->PADJ_R = cpv(h, CP_PADJ_R, c); sc->PADJ_S = cpv(h, CP_PADJ_S, c);
+  sc->GLAC_SURF_THICK = cpv(h, CP_GLAC_SURF_THICK, c); sc->GLAC_SURF_WE = cpv(h, CP_GLAC_SURF_WE, c);
+  sc->GLAC_KMIN = cpv(h, CP_GLAC_KMIN, c); sc->GLAC_DK = cpv(h, CP_GLAC_DK, c); sc->GLAC_A = cpv(h, CP_GLAC_A, c);
+  sc->GLAC_ALBEDO = cpv(h, CP_GLAC_ALBEDO, c); sc->GLAC_ROUGH = cpv(h, CP_GLAC_ROUGH, c);
+  for (int l = 0; l < 3; l++) {
+    sc->Ksat[l] = cpv(h, VICGPU_CP_LAYER(CPL_KSAT, l), c);
+    sc->Wcr[l] = cpv(h, VICGPU_CP_LAYER(CPL_WCR, l), c);
+    sc->Wpwp[l] = cpv(h, VICGPU_CP_LAYER(CPL_WPWP, l), c);
+    sc->expt[l] = cpv(h, VICGPU_CP_LAYER(CPL_EXPT, l), c);
+    sc->bubble[l] = cpv(h, VICGPU_CP_LAYER(CPL_BUBBLE, l), c);
+    sc->depth[l] = cpv(h, VICGPU_CP_LAYER(CPL_DEPTH, l), c);
+    sc->max_moist[l] = cpv(h, VICGPU_CP_LAYER(CPL_MAX_MOIST, l), c);
+    sc->resid_moist[l] = cpv(h, VICGPU_CP_LAYER(CPL_RESID_MOIST, l), c);
+    sc->porosity[l] = cpv(h, VICGPU_CP_LAYER(CPL_POROSITY, l), c);
+    sc->quartz[l] = cpv(h, VICGPU_CP_LAYER(CPL_QUARTZ, l), c);
+    sc->organic[l] = cpv(h, VICGPU_CP_LAYER(CPL_ORGANIC, l), c);
+    sc->bulk_density[l] = cpv(h, VICGPU_CP_LAYER(CPL_BULK_DENSITY, l), c);
+    sc->soil_density[l] = cpv(h, VICGPU_CP_LAYER(CPL_SOIL_DENSITY, l), c);
+    sc->bulk_dens_min[l] = cpv(h, VICGPU_CP_LAYER(CPL_BULK_DENS_MIN, l), c);
+    sc->soil_dens_min[l] = cpv(h, VICGPU_CP_LAYER(CPL_SOIL_DENS_MIN, l), c);
+    sc->init_moist[l] = 0;  /* set by vicref_init_state */
+  }
+  for (int n = 0; n < Nn; n++) {
+    sc->Zsum_node[n] = cpv(h, VICGPU_CP_NODE(CPN_ZSUM, n, Nn), c);
+    sc->dz_node[n] = cpv(h, VICGPU_CP_NODE(CPN_DZ, n, Nn), c);
+    sc->alpha[n] = cpv(h, VICGPU_CP_NODE(CPN_ALPHA, n, Nn), c);
+    sc->beta[n] = cpv(h, VICGPU_CP_NODE(CPN_BETA, n, Nn), c);
+    sc->gamma[n] = cpv(h, VICGPU_CP_NODE(CPN_GAMMA, n, Nn), c);
+    sc->max_moist_node[n] = cpv(h, VICGPU_CP_NODE(CPN_MAX_MOIST, n, Nn), c);
+    sc->expt_node[n] = cpv(h, VICGPU_CP_NODE(CPN_EXPT, n, Nn), c);
+    sc->bubble_node[n] = cpv(h, VICGPU_CP_NODE(CPN_BUBBLE, n, Nn), c);
+  }
+  sc->BandElev = (float *)calloc(Nb, sizeof(float));
+  sc->AreaFract = (double *)calloc(Nb, sizeof(double));
+  sc->Pfactor = (double *)calloc(Nb, sizeof(double));
+  sc->Tfactor = (double *)calloc(Nb, sizeof(double));
+  sc->AboveTreeLine = (char *)calloc(Nb, sizeof(char));
+  for (int b = 0; b < Nb; b++) {
+    sc->AreaFract[b] = cpv(h, VICGPU_CP_BAND(CPB_AREAFRACT, b, Nn, Nb), c);
+    sc->Tfactor[b] = cpv(h, VICGPU_CP_BAND(CPB_TFACTOR, b, Nn, Nb), c);
+    sc->Pfactor[b] = cpv(h, VICGPU_CP_BAND(CPB_PFACTOR, b, Nn, Nb), c);
+    sc->BandElev[b] = (float)cpv(h, VICGPU_CP_BAND(CPB_BANDELEV, b, Nn, Nb), c);
+    sc->AboveTreeLine[b] = (char)cpv(h, VICGPU_CP_BAND(CPB_ABOVETREELINE, b, Nn, Nb), c);
+  }
+  for (int l = 0; l < VIC_NLAYER + 2; l++)
+    for (int i = 0; i < VIC_MAX_ZWTVMOIST; i++) {
+      sc->zwtvmoist_zwt[l][i] = cpv(h, VICGPU_CP_ZWT_ZWT(l, i, Nn, Nb), c);
+      sc->zwtvmoist_moist[l][i] = cpv(h, VICGPU_CP_ZWT_MOIST(l, i, Nn, Nb), c);
+    }
+  sc->frost_fract[0] = 1.0;
+  sc->gridcel = c;
+}
+
+static atmos_data_struct *make_atmos(int NR) {
+  atmos_data_struct *a = (atmos_data_struct *)calloc(1, sizeof(atmos_data_struct));
+  a->air_temp = (double *)calloc(NR + 1, sizeof(double)); a->channel_in = (double *)calloc(NR + 1, sizeof(double));
+  a->density = (double *)calloc(NR + 1, sizeof(double)); a->longwave = (double *)calloc(NR + 1, sizeof(double));
+  a->prec = (double *)calloc(NR + 1, sizeof(double)); a->pressure = (double *)calloc(NR + 1, sizeof(double));
+  a->shortwave = (double *)calloc(NR + 1, sizeof(double)); a->snowflag = (char *)calloc(NR + 1, sizeof(char));
+  a->tskc = (double *)calloc(NR + 1, sizeof(double)); a->vp = (double *)calloc(NR + 1, sizeof(double));
+  a->vpd = (double *)calloc(NR + 1, sizeof(double)); a->wind = (double *)calloc(NR + 1, sizeof(double));
+  return a;
+}
+
+int vicref_set_domain(void *hv, int ncell, int nhru, const double *cell_params, const int *hpi, const double *hpd,
+                      const int *cell_off, const int *cell_list) {
+  vicref_handle *h = (vicref_handle *)hv;
+  h->ncell = ncell; h->nhru = nhru;
+  h->cp_nrow = VICGPU_CP_NROW(h->opt.Nnode, h->opt.Nband);
+  h->cp.assign(cell_params, cell_params + (size_t)h->cp_nrow * ncell);
+  h->cell_off.assign(cell_off, cell_off + ncell + 1);
+  h->cell_list.assign(cell_list, cell_list + nhru);
+  h->hru_cell.assign(nhru, -1); h->hru_pos.assign(nhru, -1);
+  h->cells.clear(); h->cells.resize(ncell);
+  for (int c = 0; c < ncell; c++) {
+    cell_info_struct &cell = h->cells[c];
+    fill_soil_con(h, c, &cell.soil_con);
+    memset(&cell.lake_con, 0, sizeof(cell.lake_con));
+    cell.lake_con.lake_idx = -1;
+    cell.atmos = make_atmos(h->NR);
+    int n = cell_off[c + 1] - cell_off[c];
+    cell.prcp.hruList.resize(n);
+    for (int k = 0; k < n; k++) {
+      int g = cell_list[cell_off[c] + k];
+      if (hpi[(size_t)HPI_CELL * nhru + g] != c) return -2;
+      h->hru_cell[g] = c; h->hru_pos[g] = k;
+      HRU &hru = cell.prcp.hruList[k];
+      /* the HRU struct has no full constructor: zero the POD members */
+      memset(&hru.cell, 0, sizeof(hru.cell));
+      memset(&hru.energy, 0, sizeof(hru.energy));
+      memset(&hru.snow, 0, sizeof(hru.snow));
+      memset(&hru.veg_var, 0, sizeof(hru.veg_var));
+      hru.glacier = glac_data_struct();
+      hru.veg_con.Cv = hpd[(size_t)HPD_CV * nhru + g];
+      for (int l = 0; l < 3; l++) hru.veg_con.root[l] = (float)hpd[(size_t)(HPD_ROOT0 + l) * nhru + g];
+      hru.veg_con.vegIndex = hpi[(size_t)HPI_VEG_INDEX * nhru + g];
+      hru.veg_con.vegClass = hpi[(size_t)HPI_VEG_CLASS * nhru + g];
+      hru.veg_con.sigma_slope = 0.08f; hru.veg_con.lag_one = 0.95f; hru.veg_con.fetch = 1000.f;
+      hru.veg_con.LAKE = 0;
+      hru.veg_con.zone_depth = NULL; hru.veg_con.zone_fract = NULL;
+      hru.init_STILL_STORM = 0; hru.init_DRY_TIME = 0;
+      hru.mu = 1.0;
+      hru.isGlacier = hpi[(size_t)HPI_IS_GLACIER * nhru + g] != 0;
+      hru.isArtificialBareSoil = hpi[(size_t)HPI_IS_ARTIFICIAL_BARE * nhru + g] != 0;
+      hru.bandIndex = hpi[(size_t)HPI_BAND * nhru + g];
+      cell.Cv_sum += hru.veg_con.Cv;
+    }
+  }
+  for (int g = 0; g < nhru; g++) if (h->hru_cell[g] < 0) return -3;
+  return 0;
+}
+
+static void load_atmos(vicref_handle *h, int c, const double *forcing, const unsigned char *snowflag) {
+  /* forcing [VIC_NFORCE][NF+1][ncell] for ONE step */
+  const int ns = h->NR + 1; const int nc = h->ncell;
+  atmos_data_struct *a = h->cells[c].atmos;
+  for (int s = 0; s < ns; s++) {
+#define FV(v) forcing[((size_t)(v) * ns + s) * nc + c]
+    a->air_temp[s] = FV(VIC_F_AIR_TEMP); a->prec[s] = FV(VIC_F_PREC); a->pressure[s] = FV(VIC_F_PRESSURE);
+    a->vp[s] = FV(VIC_F_VP); a->vpd[s] = FV(VIC_F_VPD); a->density[s] = FV(VIC_F_DENSITY);
+    a->shortwave[s] = FV(VIC_F_SHORTWAVE); a->longwave[s] = FV(VIC_F_LONGWAVE); a->wind[s] = FV(VIC_F_WIND);
+#undef FV
+    a->snowflag[s] = snowflag ? (char)snowflag[(size_t)s * nc + c] : 0;
+    a->channel_in[s] = 0; a->tskc[s] = 0;
+  }
+}
+
+/* initialize_model_state for every cell (vicNl.c:420-427 -> initializeCell); init_moist [3][ncell] */
+int vicref_init_state(void *hv, const double *forcing0, const int *dmy0, const double *init_moist) {
+  vicref_handle *h = (vicref_handle *)hv;
+  dmy_struct d; d.month = dmy0[VIC_DMY_MONTH]; d.day_in_year = dmy0[VIC_DMY_DAY_IN_YEAR]; d.hour = dmy0[VIC_DMY_HOUR];
+  d.day = dmy0[VIC_DMY_DAY]; d.year = dmy0[VIC_DMY_YEAR];
+  filep_struct filep; memset(&filep, 0, sizeof(filep));
+  for (int c = 0; c < h->ncell; c++) {
+    cell_info_struct &cell = h->cells[c];
+    for (int l = 0; l < 3; l++) cell.soil_con.init_moist[l] = init_moist[(size_t)l * h->ncell + c];
+    load_atmos(h, c, forcing0, NULL);
+    int err = initialize_model_state(&cell, d, filep, 1, "", &h->state);
+    if (err == ERROR) return -1;
+  }
+  return 0;
+}
+
+/* export the (possibly init-modified) cell parameter table: node geometry and node constants are
+ * written by initialize_model_state -> set_node_parameters (soil_conduction.c:142-303) */
+int vicref_get_cell_params(void *hv, double *out) {
+  vicref_handle *h = (vicref_handle *)hv;
+  const int Nn = h->opt.Nnode; const int nc = h->ncell;
+  memcpy(out, h->cp.data(), sizeof(double) * h->cp.size());
+  for (int c = 0; c < nc; c++) {
+    const soil_con_struct &sc = h->cells[c].soil_con;
+    for (int n = 0; n < Nn; n++) {
+      out[(size_t)VICGPU_CP_NODE(CPN_ZSUM, n, Nn) * nc + c] = sc.Zsum_node[n];
+      out[(size_t)VICGPU_CP_NODE(CPN_DZ, n, Nn) * nc + c] = sc.dz_node[n];
+      out[(size_t)VICGPU_CP_NODE(CPN_ALPHA, n, Nn) * nc + c] = sc.alpha[n];
+      out[(size_t)VICGPU_CP_NODE(CPN_BETA, n, Nn) * nc + c] = sc.beta[n];
+      out[(size_t)VICGPU_CP_NODE(CPN_GAMMA, n, Nn) * nc + c] = sc.gamma[n];
+      out[(size_t)VICGPU_CP_NODE(CPN_MAX_MOIST, n, Nn) * nc + c] = sc.max_moist_node[n];
+      out[(size_t)VICGPU_CP_NODE(CPN_EXPT, n, Nn) * nc + c] = sc.expt_node[n];
+      out[(size_t)VICGPU_CP_NODE(CPN_BUBBLE, n, Nn) * nc + c] = sc.bubble_node[n];
+    }
+  }
+  return 0;
+}
+
+#define SDP(row) sd[(size_t)(row) * nh + g]
+#define SIP(row) si[(size_t)(row) * nh + g]
+
+int vicref_get_state(void *hv, double *sd, int *si) {
+  vicref_handle *h = (vicref_handle *)hv;
+  const int Nn = h->opt.Nnode; const size_t nh = h->nhru;
+  for (int g = 0; g < h->nhru; g++) {
+    const HRU &u = h->cells[h->hru_cell[g]].prcp.hruList[h->hru_pos[g]];
+    const hru_data_struct &cw = u.cell[WET];
+    for (int l = 0; l < 3; l++) {
+      SDP(SD_MOIST0 + l) = cw.layer[l].moist; SDP(SD_ICE0 + l) = cw.layer[l].soil_ice; SDP(SD_LAYER_T0 + l) = cw.layer[l].T;
+    }
+    const energy_bal_struct &e = u.energy;
+    SDP(SD_SNOW_FLUX) = e.snow_flux; SDP(SD_GRND_FLUX) = e.grnd_flux; SDP(SD_DELTAH) = e.deltaH; SDP(SD_FUSION) = e.fusion;
+    SDP(SD_LONGUNDEROUT) = e.LongUnderOut; SDP(SD_TFOLIAGE) = e.Tfoliage;
+    const snow_data_struct &s = u.snow;
+    SDP(SD_SNOW_ALBEDO) = s.albedo; SDP(SD_SNOW_COLDCONTENT) = s.coldcontent; SDP(SD_SNOW_COVERAGE) = s.coverage;
+    SDP(SD_SNOW_DENSITY) = s.density; SDP(SD_SNOW_DEPTH) = s.depth; SDP(SD_SNOW_PACK_TEMP) = s.pack_temp;
+    SDP(SD_SNOW_PACK_WATER) = s.pack_water; SDP(SD_SNOW_CANOPY) = s.snow_canopy; SDP(SD_SNOW_SURF_TEMP) = s.surf_temp;
+    SDP(SD_SNOW_SURF_WATER) = s.surf_water; SDP(SD_SNOW_SWQ) = s.swq; SDP(SD_SNOW_TMP_INT_STORAGE) = s.tmp_int_storage;
+    SDP(SD_SNOW_STORE_SWQ) = s.store_swq; SDP(SD_SNOW_STORE_COVERAGE) = s.store_coverage; SDP(SD_SNOW_SWQ_SLOPE) = s.swq_slope;
+    SDP(SD_SNOW_MAX_SWQ) = s.max_swq;
+    SDP(SD_WDEW) = u.veg_var[WET].Wdew;
+    SDP(SD_GLAC_SURF_TEMP) = u.glacier.surf_temp; SDP(SD_GLAC_WATER_STORAGE) = u.glacier.water_storage;
+    SDP(SD_GLAC_CUM_MASS_BALANCE) = u.glacier.cum_mass_balance;
+    SDP(SD_TCANOPY) = e.Tcanopy; SDP(SD_TSURF) = e.Tsurf; SDP(SD_ALBEDO_OVER) = e.AlbedoOver; SDP(SD_ALBEDO_UNDER) = e.AlbedoUnder;
+    SDP(SD_CANOPY_ADVECTION) = e.canopy_advection; SDP(SD_CANOPY_LATENT) = e.canopy_latent;
+    SDP(SD_CANOPY_LATENT_SUB) = e.canopy_latent_sub; SDP(SD_CANOPY_SENSIBLE) = e.canopy_sensible;
+    SDP(SD_CANOPY_REFREEZE) = e.canopy_refreeze; SDP(SD_ADVECTED_SENSIBLE) = e.advected_sensible;
+    SDP(SD_ADVECTION) = e.advection; SDP(SD_DELTACC) = e.deltaCC; SDP(SD_REFREEZE_ENERGY) = e.refreeze_energy;
+    SDP(SD_MELT_ENERGY) = e.melt_energy; SDP(SD_ERROR) = e.error;
+    SDP(SD_LATENT) = e.latent; SDP(SD_LATENT_SUB) = e.latent_sub; SDP(SD_SENSIBLE) = e.sensible;
+    SDP(SD_LONGOVERIN) = e.LongOverIn; SDP(SD_NETLONGOVER) = e.NetLongOver; SDP(SD_NETSHORTOVER) = e.NetShortOver;
+    SDP(SD_SHORTOVERIN) = e.ShortOverIn;
+    for (int n = 0; n < Nn; n++) {
+      SDP(VICGPU_SD_NODE(SDN_T, n, Nn)) = e.T[n]; SDP(VICGPU_SD_NODE(SDN_MOIST, n, Nn)) = e.moist[n];
+      SDP(VICGPU_SD_NODE(SDN_ICE, n, Nn)) = e.ice_content[n]; SDP(VICGPU_SD_NODE(SDN_KAPPA, n, Nn)) = e.kappa_node[n];
+      SDP(VICGPU_SD_NODE(SDN_CS, n, Nn)) = e.Cs_node[n];
+      SIP(VICGPU_SI_NODE(SIN_T_FBFLAG, n, Nn)) = e.T_fbflag[n]; SIP(VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn)) = e.T_fbcount[n];
+    }
+    SIP(SI_SNOW_LAST_SNOW) = s.last_snow; SIP(SI_SNOW_MELTING) = s.MELTING ? 1 : 0; SIP(SI_SNOW_SNOW) = s.snow;
+    SIP(SI_SNOW_STORE_SNOW) = s.store_snow; SIP(SI_SNOW_SURF_TEMP_FBCOUNT) = s.surf_temp_fbcount;
+    SIP(SI_SNOW_SURF_TEMP_FBFLAG) = s.surf_temp_fbflag ? 1 : 0;
+    SIP(SI_TSURF_FBCOUNT) = e.Tsurf_fbcount; SIP(SI_TSURF_FBFLAG) = e.Tsurf_fbflag;
+    SIP(SI_TFOLIAGE_FBCOUNT) = e.Tfoliage_fbcount; SIP(SI_TFOLIAGE_FBFLAG) = e.Tfoliage_fbflag;
+    SIP(SI_TCANOPY_FBCOUNT) = e.Tcanopy_fbcount; SIP(SI_TCANOPY_FBFLAG) = e.Tcanopy_fbflag;
+    SIP(SI_GLAC_SURF_TEMP_FBCOUNT) = u.glacier.surf_temp_fbcount; SIP(SI_GLAC_SURF_TEMP_FBFLAG) = u.glacier.surf_temp_fbflag ? 1 : 0;
+    SIP(SI_FROZEN) = e.frozen; SIP(SI_NFROST) = e.Nfrost; SIP(SI_NTHAW) = e.Nthaw;
+  }
+  return 0;
+}
+
+int vicref_set_state(void *hv, const double *sd, const int *si) {
+  vicref_handle *h = (vicref_handle *)hv;
+  const int Nn = h->opt.Nnode; const size_t nh = h->nhru;
+  for (int g = 0; g < h->nhru; g++) {
+    HRU &u = h->cells[h->hru_cell[g]].prcp.hruList[h->hru_pos[g]];
+    hru_data_struct &cw = u.cell[WET];
+    for (int l = 0; l < 3; l++) {
+      cw.layer[l].moist = SDP(SD_MOIST0 + l); cw.layer[l].soil_ice = SDP(SD_ICE0 + l); cw.layer[l].T = SDP(SD_LAYER_T0 + l);
+    }
+    energy_bal_struct &e = u.energy;
+    e.snow_flux = SDP(SD_SNOW_FLUX); e.grnd_flux = SDP(SD_GRND_FLUX); e.deltaH = SDP(SD_DELTAH); e.fusion = SDP(SD_FUSION);
+    e.LongUnderOut = SDP(SD_LONGUNDEROUT); e.Tfoliage = SDP(SD_TFOLIAGE);
+    snow_data_struct &s = u.snow;
+    s.albedo = SDP(SD_SNOW_ALBEDO); s.coldcontent = SDP(SD_SNOW_COLDCONTENT); s.coverage = SDP(SD_SNOW_COVERAGE);
+    s.density = SDP(SD_SNOW_DENSITY); s.depth = SDP(SD_SNOW_DEPTH); s.pack_temp = SDP(SD_SNOW_PACK_TEMP);
+    s.pack_water = SDP(SD_SNOW_PACK_WATER); s.snow_canopy = SDP(SD_SNOW_CANOPY); s.surf_temp = SDP(SD_SNOW_SURF_TEMP);
+    s.surf_water = SDP(SD_SNOW_SURF_WATER); s.swq = SDP(SD_SNOW_SWQ); s.tmp_int_storage = SDP(SD_SNOW_TMP_INT_STORAGE);
+    s.store_swq = SDP(SD_SNOW_STORE_SWQ); s.store_coverage = SDP(SD_SNOW_STORE_COVERAGE); s.swq_slope = SDP(SD_SNOW_SWQ_SLOPE);
+    s.max_swq = SDP(SD_SNOW_MAX_SWQ);
+    u.veg_var[WET].Wdew = SDP(SD_WDEW);
+    u.glacier.surf_temp = SDP(SD_GLAC_SURF_TEMP); u.glacier.water_storage = SDP(SD_GLAC_WATER_STORAGE);
+    u.glacier.cum_mass_balance = SDP(SD_GLAC_CUM_MASS_BALANCE);
+    e.Tcanopy = SDP(SD_TCANOPY); e.Tsurf = SDP(SD_TSURF); e.AlbedoOver = SDP(SD_ALBEDO_OVER); e.AlbedoUnder = SDP(SD_ALBEDO_UNDER);
+    e.canopy_advection = SDP(SD_CANOPY_ADVECTION); e.canopy_latent = SDP(SD_CANOPY_LATENT);
+    e.canopy_latent_sub = SDP(SD_CANOPY_LATENT_SUB); e.canopy_sensible = SDP(SD_CANOPY_SENSIBLE);
+    e.canopy_refreeze = SDP(SD_CANOPY_REFREEZE); e.advected_sensible = SDP(SD_ADVECTED_SENSIBLE);
+    e.advection = SDP(SD_ADVECTION); e.deltaCC = SDP(SD_DELTACC); e.refreeze_energy = SDP(SD_REFREEZE_ENERGY);
+    e.melt_energy = SDP(SD_MELT_ENERGY); e.error = SDP(SD_ERROR);
+    e.latent = SDP(SD_LATENT); e.latent_sub = SDP(SD_LATENT_SUB); e.sensible = SDP(SD_SENSIBLE);
+    e.LongOverIn = SDP(SD_LONGOVERIN); e.NetLongOver = SDP(SD_NETLONGOVER); e.NetShortOver = SDP(SD_NETSHORTOVER);
+    e.ShortOverIn = SDP(SD_SHORTOVERIN);
+    for (int n = 0; n < Nn; n++) {
+      e.T[n] = SDP(VICGPU_SD_NODE(SDN_T, n, Nn)); e.moist[n] = SDP(VICGPU_SD_NODE(SDN_MOIST, n, Nn));
+      e.ice_content[n] = SDP(VICGPU_SD_NODE(SDN_ICE, n, Nn)); e.kappa_node[n] = SDP(VICGPU_SD_NODE(SDN_KAPPA, n, Nn));
+      e.Cs_node[n] = SDP(VICGPU_SD_NODE(SDN_CS, n, Nn));
+      e.T_fbflag[n] = (char)SIP(VICGPU_SI_NODE(SIN_T_FBFLAG, n, Nn)); e.T_fbcount[n] = SIP(VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn));
+    }
+    s.last_snow = SIP(SI_SNOW_LAST_SNOW); s.MELTING = SIP(SI_SNOW_MELTING) != 0; s.snow = SIP(SI_SNOW_SNOW);
+    s.store_snow = SIP(SI_SNOW_STORE_SNOW); s.surf_temp_fbcount = SIP(SI_SNOW_SURF_TEMP_FBCOUNT);
+    s.surf_temp_fbflag = SIP(SI_SNOW_SURF_TEMP_FBFLAG) != 0;
+    e.Tsurf_fbcount = SIP(SI_TSURF_FBCOUNT); e.Tsurf_fbflag = (char)SIP(SI_TSURF_FBFLAG);
+    e.Tfoliage_fbcount = SIP(SI_TFOLIAGE_FBCOUNT); e.Tfoliage_fbflag = (char)SIP(SI_TFOLIAGE_FBFLAG);
+    e.Tcanopy_fbcount = SIP(SI_TCANOPY_FBCOUNT); e.Tcanopy_fbflag = (char)SIP(SI_TCANOPY_FBFLAG);
+    u.glacier.surf_temp_fbcount = SIP(SI_GLAC_SURF_TEMP_FBCOUNT); u.glacier.surf_temp_fbflag = SIP(SI_GLAC_SURF_TEMP_FBFLAG) != 0;
+    e.frozen = (char)SIP(SI_FROZEN); e.Nfrost = SIP(SI_NFROST); e.Nthaw = SIP(SI_NTHAW);
+  }
+  return 0;
+}
+
+static void export_flux(vicref_handle *h, double *fx, double *cell_out, const int *cell_err) {
+  const size_t nh = h->nhru;
+  for (int g = 0; g < h->nhru; g++) {
+    const HRU &u = h->cells[h->hru_cell[g]].prcp.hruList[h->hru_pos[g]];
+    const hru_data_struct &cw = u.cell[WET];
+    const energy_bal_struct &e = u.energy; const snow_data_struct &s = u.snow;
+#define FXP(row) fx[(size_t)(row) * nh + g]
+    FXP(FX_RUNOFF) = cw.runoff; FXP(FX_BASEFLOW) = cw.baseflow; FXP(FX_ASAT) = cw.asat; FXP(FX_INFLOW) = cw.inflow;
+    for (int l = 0; l < 3; l++) FXP(FX_EVAP0 + l) = cw.layer[l].evap;
+    FXP(FX_CANOPYEVAP) = u.veg_var[WET].canopyevap; FXP(FX_THROUGHFALL) = u.veg_var[WET].throughfall;
+    FXP(FX_SNOW_VAPOR_FLUX) = s.vapor_flux; FXP(FX_SNOW_CANOPY_VAPOR_FLUX) = s.canopy_vapor_flux;
+    FXP(FX_SNOW_BLOWING_FLUX) = s.blowing_flux; FXP(FX_SNOW_SURFACE_FLUX) = s.surface_flux;
+    FXP(FX_SNOW_MELT) = s.melt; FXP(FX_SNOW_MASS_ERROR) = s.mass_error; FXP(FX_SNOW_QNET) = s.Qnet;
+    for (int p = 0; p < 6; p++) FXP(FX_POT_EVAP0 + p) = cw.pot_evap[p];
+    FXP(FX_AERO_RESIST_SURFACE) = cw.aero_resist.surface; FXP(FX_AERO_RESIST_OVERSTORY) = cw.aero_resist.overstory;
+    FXP(FX_ROOTMOIST) = cw.rootmoist; FXP(FX_WETNESS) = cw.wetness;
+    FXP(FX_ZWT) = cw.zwt; FXP(FX_ZWT2) = cw.zwt2; FXP(FX_ZWT3) = cw.zwt3;
+    FXP(FX_ATMOS_LATENT) = e.AtmosLatent; FXP(FX_ATMOS_LATENT_SUB) = e.AtmosLatentSub; FXP(FX_ATMOS_SENSIBLE) = e.AtmosSensible;
+    FXP(FX_LONG_UNDER_IN) = e.LongUnderIn; FXP(FX_NET_LONG_ATMOS) = e.NetLongAtmos; FXP(FX_NET_LONG_UNDER) = e.NetLongUnder;
+    FXP(FX_NET_SHORT_ATMOS) = e.NetShortAtmos; FXP(FX_NET_SHORT_GRND) = e.NetShortGrnd; FXP(FX_NET_SHORT_UNDER) = e.NetShortUnder;
+    FXP(FX_SHORT_UNDER_IN) = e.ShortUnderIn;
+    FXP(FX_OUT_PREC) = NAN; FXP(FX_OUT_RAIN) = NAN; FXP(FX_OUT_SNOW) = NAN;  /* not observable per HRU in the reference */
+    FXP(FX_GLAC_MASS_BALANCE) = u.glacier.mass_balance; FXP(FX_GLAC_ICE_MASS_BALANCE) = u.glacier.ice_mass_balance;
+    FXP(FX_GLAC_ACCUMULATION) = u.glacier.accumulation; FXP(FX_GLAC_MELT) = u.glacier.melt;
+    FXP(FX_GLAC_VAPOR_FLUX) = u.glacier.vapor_flux; FXP(FX_GLAC_INFLOW) = u.glacier.inflow;
+    FXP(FX_GLAC_OUTFLOW) = u.glacier.outflow; FXP(FX_GLAC_OUTFLOW_COEF) = u.glacier.outflow_coef;
+    FXP(FX_GLAC_QNET) = u.glacier.Qnet; FXP(FX_GLAC_COLD_CONTENT) = u.glacier.cold_content;
+    FXP(FX_GLACIER_FLUX) = e.glacier_flux; FXP(FX_DELTACC_GLAC) = e.deltaCC_glac; FXP(FX_GLACIER_MELT_ENERGY) = e.glacier_melt_energy;
+#undef FXP
+  }
+  if (cell_out) for (int c = 0; c < h->ncell; c++) {
+    const atmos_data_struct *a = h->cells[c].atmos;
+    cell_out[(size_t)CO_OUT_PREC * h->ncell + c] = a->out_prec;
+    cell_out[(size_t)CO_OUT_RAIN * h->ncell + c] = a->out_rain;
+    cell_out[(size_t)CO_OUT_SNOW * h->ncell + c] = a->out_snow;
+  }
+  (void)cell_err;
+}
+
+/* One model step for every cell: the body of the OpenMP loop vicNl.c:514-563 without put_data.
+ * forcing [VIC_NFORCE][NF+1][ncell], snowflag [NF+1][ncell], dmy [VIC_NDMY].
+ * flux / cell_out / cell_err may be NULL. Returns the number of cells that returned ERROR. */
+int vicref_step(void *hv, const double *forcing, const unsigned char *snowflag, const int *dmyv,
+                double *flux, double *cell_out, int *cell_err, int nthreads) {
+  vicref_handle *h = (vicref_handle *)hv;
+  dmy_struct d; d.month = dmyv[VIC_DMY_MONTH]; d.day_in_year = dmyv[VIC_DMY_DAY_IN_YEAR]; d.hour = dmyv[VIC_DMY_HOUR];
+  d.day = dmyv[VIC_DMY_DAY]; d.year = dmyv[VIC_DMY_YEAR];
+  int nerr = 0;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 16) reduction(+:nerr)
+  for (int c = 0; c < h->ncell; c++) {
+    cell_info_struct &cell = h->cells[c];
+    load_atmos(h, c, forcing, snowflag);
+    int err = full_energy(FALSE, 0, cell.atmos, &cell.prcp, &d, &cell.lake_con, &cell.soil_con, &cell.writeDebug, &h->state);
+    if (cell_err) cell_err[c] = (err == ERROR) ? VICGPU_CELLERR_SOLVER : 0;
+    if (err == ERROR) nerr++;
+    /* accumulateGlacierMassBalance (vicNl.c:562-563) is a host-side += of glacier.mass_balance; the
+       accumulation-window logic is driver state, so the harness applies the += unconditionally once
+       cum_mass_balance has been made valid by the caller */
+    for (std::vector<HRU>::iterator it = cell.prcp.hruList.begin(); it != cell.prcp.hruList.end(); ++it)
+      if (it->isGlacier && IS_VALID(it->glacier.cum_mass_balance) && IS_VALID(it->glacier.mass_balance))
+        it->glacier.cum_mass_balance += it->glacier.mass_balance;
+  }
+  if (flux) export_flux(h, flux, cell_out, cell_err);
+  return nerr;
+}
+
+/* Timed multi-step run for bench.py's cpu_baseline leg: forcing [nsteps][VIC_NFORCE][NF+1][ncell].
+ * Returns wall seconds. */
+double vicref_run(void *hv, int nsteps, const double *forcing, const unsigned char *snowflag, const int *dmyv, int nthreads) {
+  vicref_handle *h = (vicref_handle *)hv;
+  const size_t fstride = (size_t)VIC_NFORCE * (h->NR + 1) * h->ncell;
+  const size_t sstride = (size_t)(h->NR + 1) * h->ncell;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int s = 0; s < nsteps; s++)
+    vicref_step(hv, forcing + s * fstride, snowflag ? snowflag + s * sstride : NULL, dmyv + (size_t)s * VIC_NDMY, NULL, NULL, NULL, nthreads);
+  auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+
+int vicref_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+} /* extern "C" */
