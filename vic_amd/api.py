@@ -1,0 +1,187 @@
+"""Host-side binding of the C-ABI in include/vicgpu.h (libvicgpu.so, HIP/gfx950).
+
+The method names mirror the reference driver's vocabulary for this path
+(vicNl.c:390-654 runModel / dist_prec.c:8 dist_prec): a `Model` owns the domain
+tables on one GPU, `push_forcing` replaces cell.atmos[rec], `dist_prec(rec0, n)`
+advances every cell n records.  There is NO CPU fallback: if the HIP library is
+missing or no GPU is visible, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import abi
+from .abi import C
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvicgpu.so")
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_up = ctypes.POINTER(ctypes.c_ubyte)
+
+_lib = None
+
+
+class VicGpuError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Loads libvicgpu.so and declares every entry point of include/vicgpu.h.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VicGpuError("HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp = ctypes.c_void_p
+    sig = {
+        "vicgpu_abi_version": (ctypes.c_int, []),
+        "vicgpu_create": (ctypes.c_int, [ctypes.POINTER(abi.Options), ctypes.c_int, ctypes.POINTER(vp)]),
+        "vicgpu_destroy": (None, [vp]),
+        "vicgpu_last_error": (ctypes.c_char_p, [vp]),
+        "vicgpu_set_veglib": (ctypes.c_int, [vp, ctypes.c_int, _dp]),
+        "vicgpu_set_domain": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, _dp, _ip, _dp, _ip, _ip]),
+        "vicgpu_set_state": (ctypes.c_int, [vp, _dp, _ip]),
+        "vicgpu_get_state": (ctypes.c_int, [vp, _dp, _ip]),
+        "vicgpu_push_forcing": (ctypes.c_int, [vp, ctypes.c_int, _dp, _up, _ip]),
+        "vicgpu_step": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int]),
+        "vicgpu_synchronize": (ctypes.c_int, [vp]),
+        "vicgpu_get_fluxes": (ctypes.c_int, [vp, _dp]),
+        "vicgpu_get_cell_outputs": (ctypes.c_int, [vp, _dp]),
+        "vicgpu_get_accum": (ctypes.c_int, [vp, _dp]),
+        "vicgpu_reset_accum": (ctypes.c_int, [vp]),
+        "vicgpu_get_cell_errors": (ctypes.c_int, [vp, _ip]),
+        "vicgpu_set_stream": (ctypes.c_int, [vp, vp]),
+        "vicgpu_set_write_fluxes": (ctypes.c_int, [vp, ctypes.c_int]),
+        "vicgpu_device_ptr": (vp, [vp, ctypes.c_int]),
+        "vicgpu_last_kernel_ms": (ctypes.c_int, [vp, _dp, _ip]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    if lib.vicgpu_abi_version() != C["VICGPU_ABI_VERSION"]:
+        raise VicGpuError("ABI version mismatch between include/vicgpu.h and libvicgpu.so")
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "vicgpu_abi_version", "vicgpu_create", "vicgpu_destroy", "vicgpu_last_error", "vicgpu_set_veglib", "vicgpu_set_domain",
+    "vicgpu_set_state", "vicgpu_get_state", "vicgpu_push_forcing", "vicgpu_step", "vicgpu_synchronize", "vicgpu_get_fluxes",
+    "vicgpu_get_cell_outputs", "vicgpu_get_accum", "vicgpu_reset_accum", "vicgpu_get_cell_errors", "vicgpu_set_stream",
+    "vicgpu_set_write_fluxes", "vicgpu_device_ptr", "vicgpu_last_kernel_ms",
+]
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+class Model:
+    """One domain (or one rank's shard of it) resident on one GPU."""
+
+    def __init__(self, dom, device=0):
+        self.lib = load_library()
+        self.dom = dom
+        self.opt = dom.opt
+        h = ctypes.c_void_p()
+        rc = self.lib.vicgpu_create(ctypes.byref(dom.opt), device, ctypes.byref(h))
+        if rc != 0:
+            raise VicGpuError("vicgpu_create failed with code %d (no GPU, or unsupported options)" % rc)
+        self.h = h
+        self._chk(self.lib.vicgpu_set_veglib(h, dom.veglib.shape[0], _d(np.ascontiguousarray(dom.veglib))))
+        self._chk(self.lib.vicgpu_set_domain(h, dom.ncell, dom.nhru, _d(dom.cell_params), _i(dom.hru_iparams),
+                                             _d(dom.hru_dparams), _i(dom.cell_hru_offset), _i(dom.cell_hru_list)))
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.lib.vicgpu_last_error(self.h)
+            raise VicGpuError("vicgpu call failed (%d): %s" % (rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vicgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state (initialize_model_state result in / write_model_state content out)
+    def set_state(self, sd, si):
+        sd = np.ascontiguousarray(sd, dtype=np.float64)
+        si = np.ascontiguousarray(si, dtype=np.int32)
+        assert sd.shape == (abi.sd_nrow(self.opt.Nnode), self.dom.nhru), sd.shape
+        assert si.shape == (abi.si_nrow(self.opt.Nnode), self.dom.nhru), si.shape
+        self._chk(self.lib.vicgpu_set_state(self.h, _d(sd), _i(si)))
+
+    def get_state(self):
+        sd = np.zeros((abi.sd_nrow(self.opt.Nnode), self.dom.nhru))
+        si = np.zeros((abi.si_nrow(self.opt.Nnode), self.dom.nhru), dtype=np.int32)
+        self._chk(self.lib.vicgpu_get_state(self.h, _d(sd), _i(si)))
+        return sd, si
+
+    # ---- forcing chunk
+    def push_forcing(self, forcing, snowflag, dmy):
+        forcing = np.ascontiguousarray(forcing, dtype=np.float64)
+        snowflag = np.ascontiguousarray(snowflag, dtype=np.uint8)
+        dmy = np.ascontiguousarray(dmy, dtype=np.int32)
+        n = forcing.shape[0]
+        assert forcing.shape == (n, C["VIC_NFORCE"], self.opt.NR + 1, self.dom.ncell), forcing.shape
+        assert snowflag.shape == (n, self.opt.NR + 1, self.dom.ncell)
+        assert dmy.shape == (n, C["VIC_NDMY"])
+        self._hold = (forcing, snowflag, dmy)   # the H2D copy is asynchronous
+        self._chk(self.lib.vicgpu_push_forcing(self.h, n, _d(forcing), snowflag.ctypes.data_as(_up), _i(dmy)))
+
+    # ---- the hot path
+    def dist_prec(self, rec0, nrec=1, sync=True):
+        """dist_prec (dist_prec.c:8) for every cell, records [rec0, rec0+nrec) of the pushed chunk."""
+        self._chk(self.lib.vicgpu_step(self.h, rec0, nrec))
+        if sync:
+            self._chk(self.lib.vicgpu_synchronize(self.h))
+
+    def synchronize(self):
+        self._chk(self.lib.vicgpu_synchronize(self.h))
+
+    # ---- outputs
+    def get_fluxes(self):
+        fx = np.zeros((C["FX_NROW"], self.dom.nhru))
+        self._chk(self.lib.vicgpu_get_fluxes(self.h, _d(fx)))
+        return fx
+
+    def get_cell_outputs(self):
+        co = np.zeros((C["CO_NROW"], self.dom.ncell))
+        self._chk(self.lib.vicgpu_get_cell_outputs(self.h, _d(co)))
+        return co
+
+    def get_accum(self):
+        ac = np.zeros((C["CA_NROW"], self.dom.ncell))
+        self._chk(self.lib.vicgpu_get_accum(self.h, _d(ac)))
+        return ac
+
+    def reset_accum(self):
+        self._chk(self.lib.vicgpu_reset_accum(self.h))
+
+    def get_cell_errors(self):
+        ce = np.zeros(self.dom.ncell, dtype=np.int32)
+        self._chk(self.lib.vicgpu_get_cell_errors(self.h, _i(ce)))
+        return ce
+
+    def set_write_fluxes(self, on):
+        self._chk(self.lib.vicgpu_set_write_fluxes(self.h, int(bool(on))))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_double(0)
+        n = ctypes.c_int(0)
+        self._chk(self.lib.vicgpu_last_kernel_ms(self.h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,35 @@
+"""Builds the HIP extension vic_amd/libvicgpu.so for gfx950 (in-tree, so it travels with the repo snapshot)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "vicgpu_api.hip")
+OUT = os.path.join(HERE, "libvicgpu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))] + [os.path.join(ROOT, "include", "vicgpu.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, extra=(), verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [HIPCC] + FLAGS + list(extra) + [SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    extra = [a for a in sys.argv[1:] if a != "-f"]
+    build(force="-f" in sys.argv, extra=extra, verbose=True)

@@ -1,0 +1,342 @@
+// vic_math.hpp — leaf physics and the SIMT root finder (device only, gfx950).
+// Reference citations are pacificclimate/VIC file:line of the algorithm each function computes.
+#pragma once
+#include "vic_types.hpp"
+
+namespace vic {
+
+// svp.c:7-24 — saturation vapour pressure (Pa)
+VIC_DEV double svp(double T) {
+  double s = 0.61078 * exp((17.269 * T) / (237.3 + T));
+  if (T < 0) s *= 1.0 + .00972 * T + .000042 * T * T;
+  return s * 1000.;
+}
+// svp.c:26-34
+VIC_DEV double svp_slope(double T) { return (17.269 * 237.3) / ((237.3 + T) * (237.3 + T)) * svp(T); }
+
+// penman.c:44-95
+VIC_DEV double calc_rc(double rs, double net_short, float RGL, double tair, double vpd, double lai, double gsm_inv, bool ref_crop) {
+  const double CLOSURE = 4000, RSMAX = 5000, VPDMINFACTOR = 0.1;
+  double rc;
+  if (rs == 0) rc = 0;
+  else if (lai == 0) rc = HUGE_RESIST;
+  else if (ref_crop) rc = rs / (lai * 0.5);
+  else {
+    double dayf, tf, vf;
+    if (rs > 0.) {
+      double f = net_short / RGL;
+      dayf = (1. + f) / (f + rs / RSMAX);
+    } else dayf = 1.;
+    tf = .08 * tair - 0.0016 * tair * tair;
+    tf = (tf <= 0.0) ? 1e-10 : tf;
+    vf = 1 - vpd / CLOSURE;
+    vf = (vf < VPDMINFACTOR) ? VPDMINFACTOR : vf;
+    rc = rs / (lai * gsm_inv * tf * vf) * dayf;
+    rc = (rc > RSMAX) ? RSMAX : rc;
+  }
+  return rc;
+}
+
+// penman.c:96-145 — Penman-Monteith (mm/day).  The parts that depend only on (tair, elevation) are split out so that
+// callers evaluating several resistances at one temperature (transpiration, pot-evap) pay for the exponentials once.
+struct PenmanBase { double slope, lv, gamma, r_air; };
+VIC_DEV PenmanBase penman_base(double tair, double elevation) {
+  PenmanBase b;
+  b.slope = svp_slope(tair);
+  double h = 287 / 9.81 * ((tair + 273.15) + 0.5 * elevation * -0.006);
+  double pz = 101300 * exp(-elevation / h);
+  b.lv = 2501000 - 2361 * tair;
+  b.gamma = 1628.6 * pz / b.lv;
+  b.r_air = 0.003486 * pz / (275 + tair);
+  return b;
+}
+VIC_DEV double penman_eval(const PenmanBase& b, double rad, double vpd, double ra, double rc, double rarc) {
+  double evap = (b.slope * rad + b.r_air * 1013 * vpd / ra) / (b.lv * (b.slope + b.gamma * (1 + (rc + rarc) / ra))) * SEC_PER_DAY;
+  if (vpd >= 0.0 && evap < 0.0) evap = 0.0;
+  return evap;
+}
+VIC_DEV double penman(double tair, double elevation, double rad, double vpd, double ra, double rc, double rarc) {
+  return penman_eval(penman_base(tair, elevation), rad, vpd, ra, rc, rarc);
+}
+
+// StabilityCorrection.c:44-81
+VIC_DEV double stability_correction(double Z, double d, double TSurf, double Tair, double Wind, double Z0) {
+  double corr = 1.0;
+  const double RiCr = 0.2;
+  if (TSurf != Tair) {
+    double Ri = G_GRAV * (Tair - TSurf) * (Z - d) / (((Tair + 273.15) + (TSurf + 273.15)) / 2.0 * Wind * Wind);
+    double RiLimit = (Tair + 273.15) / (((Tair + 273.15) + (TSurf + 273.15)) / 2.0 * (log((Z - d) / Z0) + 5));
+    if (Ri > RiLimit) Ri = RiLimit;
+    if (Ri > 0.0) corr = (1 - Ri / RiCr) * (1 - Ri / RiCr);
+    else {
+      if (Ri < -0.5) Ri = -0.5;
+      corr = sqrt(1 - 16 * Ri);
+    }
+  }
+  return corr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Root finder: Brent (1973) with the reference's bracket-expansion and ERROR-aware search
+// (root_brent.c:97-337), restructured for SIMT as a state machine with ONE residual evaluation site.
+// The reference calls the residual from eight places; inlining a residual that itself contains a soil
+// profile solve eight times is not an option on a GPU, and a single site is also what keeps the lanes
+// of a wavefront in the same instruction stream: every lane evaluates its own next abscissa in lock
+// step, finished lanes idle under the exec mask until the wave's last lane is done (the while
+// condition is the wave-level "any lane still active").  The sequence of abscissae each lane
+// evaluates is exactly the reference's.
+// ------------------------------------------------------------------------------------------------
+struct Brent {
+  enum Phase : int {
+    EVAL_A0, EVAL_B0, SEARCH0, EXP_A, EXP_B, EXP_ONE, SEARCH1, MAIN, DONE
+  };
+  double a, b, c, d, e, fa, fb, fc, last_bad, last_good, x, result;
+  int phase, which_err, i, j, k;
+
+  static constexpr int MAXTRIES = 5, MAXITER = 1000;
+  static constexpr double MACHEPS = 3e-8, TSTEP = 10, TTOL = 1e-7;
+
+  VIC_DEV void start(double lower, double upper) {
+    a = lower; b = upper; c = 0; d = 0; e = 0; fa = fb = fc = 0; last_bad = last_good = 0;
+    which_err = 0; i = j = k = 0; result = ERROR_VAL;
+    phase = EVAL_A0; x = a;
+  }
+  VIC_DEV void fail() { result = ERROR_VAL; phase = DONE; }
+
+  // bracket-expansion loop head (root_brent.c:183): decides the next evaluation or enters the main loop
+  VIC_DEV void bracket_check() {
+    if ((fa * fb) >= 0 && j < MAXTRIES) {
+      if (which_err == 0) { a -= TSTEP; b += TSTEP; phase = EXP_A; x = a; }
+      else if (which_err == -1) { b += TSTEP; phase = EXP_ONE; x = b; }
+      else { a -= TSTEP; phase = EXP_ONE; x = a; }
+    } else if ((fa * fb) >= 0) fail();                                   // :244-248
+    else { fc = fb; i = 0; main_prestep(); }
+  }
+
+  // body of the main loop up to (not including) the evaluation at the new b (root_brent.c:258-322)
+  VIC_DEV void main_prestep() {
+    if (fb * fc > 0) { c = a; fc = fa; d = b - a; e = d; }
+    if (fabs(fc) < fabs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+    double tol = 2 * MACHEPS * fabs(b) + TTOL;
+    double m = 0.5 * (c - b);
+    if (fabs(m) <= tol || fb == 0) { result = b; phase = DONE; return; }
+    if (fabs(e) < tol || fabs(fa) <= fabs(fb)) { d = m; e = d; }
+    else {
+      double p, q, r, s = fb / fa;
+      if (a == c) { p = 2 * m * s; q = 1 - s; }
+      else {
+        q = fa / fc; r = fb / fc;
+        p = s * (2 * m * q * (q - r) - (b - a) * (r - 1));
+        q = (q - 1) * (r - 1) * (s - 1);
+      }
+      if (p > 0) q = -q; else p = -p;
+      s = e; e = d;
+      if ((2 * p) < (3 * m * q - fabs(tol * q)) && p < fabs(0.5 * s * q)) d = p / q;
+      else { d = m; e = d; }
+    }
+    a = b; fa = fb;
+    b += (fabs(d) > tol) ? d : ((m > 0) ? tol : -tol);
+    phase = MAIN; x = b;
+  }
+
+  // consume the residual at x and pick the next abscissa
+  VIC_DEV void advance(double fx) {
+    switch (phase) {
+      case EVAL_A0: fa = fx; phase = EVAL_B0; x = b; break;
+      case EVAL_B0:
+        fb = fx;
+        if (fa == ERROR_VAL && fb == ERROR_VAL) { fail(); break; }                     // :129-132
+        if (fa == ERROR_VAL || fb == ERROR_VAL) {                                      // :136-150
+          if (fa == ERROR_VAL) { which_err = -1; last_bad = a; last_good = b; }
+          else { which_err = 1; last_good = a; last_bad = b; }
+          c = 0.5 * (last_bad + last_good);
+          k = 0; phase = SEARCH0; x = c;
+        } else { j = 0; bracket_check(); }
+        break;
+      case SEARCH0:                                                                    // :152-175
+        fc = fx;
+        if (fc == ERROR_VAL && k < MAXITER) { last_bad = c; c = 0.5 * (last_bad + last_good); k++; x = c; break; }
+        if (fc == ERROR_VAL) { fail(); break; }
+        if (which_err == -1) { a = c; fa = fc; } else { b = c; fb = fc; }
+        j = 0; bracket_check();
+        break;
+      case EXP_A: fa = fx; phase = EXP_B; x = b; break;                                // :186-189
+      case EXP_B: fb = fx; j++; bracket_check(); break;
+      case EXP_ONE:                                                                    // :192-215
+        if (which_err == -1) { fb = fx; if (fb == ERROR_VAL) { fail(); break; } last_good = a; }
+        else { fa = fx; if (fa == ERROR_VAL) { fail(); break; } last_good = b; }
+        c = 0.5 * (last_good + last_bad);
+        k = 0; phase = SEARCH1; x = c;
+        break;
+      case SEARCH1:                                                                    // :216-238
+        fc = fx;
+        if (fc == ERROR_VAL && k < MAXITER) { last_bad = c; c = 0.5 * (last_bad + last_good); k++; x = c; break; }
+        if (fc == ERROR_VAL) { fail(); break; }
+        if (which_err == -1) { a = c; fa = fc; } else { b = c; fb = fc; }
+        j++; bracket_check();
+        break;
+      case MAIN:                                                                       // :323-332
+        fb = fx;
+        if (fb == ERROR_VAL) { fail(); break; }
+        i++;
+        if (i >= MAXITER) { fail(); break; }
+        main_prestep();
+        break;
+      default: break;
+    }
+  }
+};
+
+template <class F>
+VIC_DEV double root_brent(double lower, double upper, F& f) {
+  Brent st;
+  st.start(lower, upper);
+  while (st.phase != Brent::DONE) {
+    double fx = f(st.x);
+    st.advance(fx);
+  }
+  return st.result;
+}
+
+// ------------------------------------------------------------------------------------------------ aerodynamics
+
+// calc_veg_params.c:26-41
+VIC_DEV double calc_veg_height(double displacement, double L) {
+  double X = COEF_DRAG * L;
+  return displacement / (1.1 * log(1 + pow(X, 0.25)));
+}
+
+// CalcAerodynamic.c:64-271; returns false on the trunk-space error (:214-217)
+VIC_DEV bool calc_aerodynamic(bool overstory, double Height, double Trunk, double Z0_SNOW, double Z0_SOIL, double n,
+                              Vc& ra, Vc& U, Vc& disp, Vc& zref, Vc& z0) {
+  const double K2 = VON_K * VON_K;
+  double tmp_wind = U.v[SNOW_FREE];
+  if (!overstory) {
+    double Z0_Lower = z0.v[SNOW_FREE], d_Lower = disp.v[SNOW_FREE];
+    double l2 = log((2. + Z0_Lower) / Z0_Lower);
+    double lr = log((zref.v[SNOW_FREE] - d_Lower) / Z0_Lower);
+    U.v[SNOW_FREE] = l2 / lr;
+    ra.v[SNOW_FREE] = l2 * lr / K2;
+    zref.v[CANOPY] = zref.v[SNOW_FREE]; z0.v[CANOPY] = z0.v[SNOW_FREE]; disp.v[CANOPY] = disp.v[SNOW_FREE];
+    U.v[CANOPY] = U.v[SNOW_FREE]; ra.v[CANOPY] = ra.v[SNOW_FREE];
+    zref.v[SNOW_COVERED] = zref.v[SNOW_FREE];
+    z0.v[SNOW_COVERED] = Z0_SNOW;
+    disp.v[SNOW_COVERED] = 0.;
+    double ls2 = log((2. + Z0_SNOW) / Z0_SNOW), lsr = log(zref.v[SNOW_COVERED] / Z0_SNOW);
+    U.v[SNOW_COVERED] = ls2 / lsr;
+    ra.v[SNOW_COVERED] = ls2 * lsr / K2;
+    zref.v[SNOW_COVERED] = 2. + Z0_SNOW;
+    zref.v[GLACIER_SURF] = zref.v[SNOW_FREE];
+    z0.v[GLACIER_SURF] = Z0_Lower;
+    disp.v[GLACIER_SURF] = 0.;
+    double lgr = log(zref.v[GLACIER_SURF] / Z0_Lower);
+    U.v[GLACIER_SURF] = l2 / lgr;
+    ra.v[GLACIER_SURF] = l2 * lgr / K2;
+    zref.v[GLACIER_SURF] = 2. + Z0_Lower;
+  } else {
+    double Z0_Upper = z0.v[SNOW_FREE], d_Upper = disp.v[SNOW_FREE];
+    double Z0_Lower = Z0_SOIL, d_Lower = 0;
+    double Zw = 1.5 * Height - 0.5 * d_Upper;
+    double Zt = Trunk * Height;
+    double zr = zref.v[SNOW_FREE];
+    if (Zt < (Z0_Lower + d_Lower)) return false;
+    double lru = log((zr - d_Upper) / Z0_Upper);
+    ra.v[CANOPY] = lru / K2 * (Height / (n * (Zw - d_Upper)) * (exp(n * (1 - (d_Upper + Z0_Upper) / Height)) - 1)
+                               + (Zw - Height) / (Zw - d_Upper) + log((zr - d_Upper) / (Zw - d_Upper)));
+    double Uw = log((Zw - d_Upper) / Z0_Upper) / lru;
+    double Uh = Uw - (1 - (Height - d_Upper) / (Zw - d_Upper)) / lru;
+    U.v[CANOPY] = Uh * exp(n * ((Z0_Upper + d_Upper) / Height - 1.));
+    double Ut = Uh * exp(n * (Zt / Height - 1.));
+    double l2 = log((2. + Z0_Lower) / Z0_Lower), ltz = log(Zt / Z0_Lower);
+    U.v[SNOW_FREE] = Ut * l2 / ltz;
+    ra.v[SNOW_FREE] = l2 * ltz / (K2 * Ut);
+    if (Zt > (2. + Z0_SNOW)) {
+      double ls2 = log((2. + Z0_SNOW) / Z0_SNOW), lts = log(Zt / Z0_SNOW);
+      U.v[SNOW_COVERED] = Ut * ls2 / lts;
+      ra.v[SNOW_COVERED] = ls2 * lts / (K2 * Ut);
+    } else if (Height > (2. + Z0_SNOW)) {
+      double lts = log(Zt / Z0_SNOW);
+      U.v[SNOW_COVERED] = Uh * exp(n * ((2. + Z0_SNOW) / Height - 1.));
+      ra.v[SNOW_COVERED] = lts * lts / (K2 * Ut)
+          + Height * lru / (n * K2 * (Zw - d_Upper)) * (exp(n * (1 - Zt / Height)) - exp(n * (1 - (Z0_SNOW + 2.) / Height)));
+    } else {
+      double lts = log(Zt / Z0_SNOW);
+      U.v[SNOW_COVERED] = Uh;
+      ra.v[SNOW_COVERED] = lts * lts / (K2 * Ut) + Height * lru / (n * K2 * (Zw - d_Upper)) * (exp(n * (1 - Zt / Height)) - 1);
+    }
+    zref.v[CANOPY] = zref.v[SNOW_FREE]; z0.v[CANOPY] = z0.v[SNOW_FREE]; disp.v[CANOPY] = disp.v[SNOW_FREE];
+    zref.v[SNOW_FREE] = 2. + Z0_Lower; z0.v[SNOW_FREE] = Z0_Lower; disp.v[SNOW_FREE] = d_Lower;
+    zref.v[SNOW_COVERED] = 2. + Z0_SNOW; z0.v[SNOW_COVERED] = Z0_SNOW; disp.v[SNOW_COVERED] = 0.;
+    zref.v[GLACIER_SURF] = 2. + Z0_Lower; z0.v[GLACIER_SURF] = Z0_Lower; disp.v[GLACIER_SURF] = 0.;
+  }
+  if (tmp_wind > 0.) {
+    U.v[SNOW_FREE] *= tmp_wind;
+    ra.v[SNOW_FREE] /= tmp_wind;
+#pragma unroll
+    for (int k = 1; k < NCASE; k++)
+      if (!isnan(U.v[k])) { U.v[k] *= tmp_wind; ra.v[k] /= tmp_wind; }
+  } else {
+    U.v[SNOW_FREE] *= tmp_wind;
+    ra.v[SNOW_FREE] = HUGE_RESIST;
+#pragma unroll
+    for (int k = 1; k < NCASE; k++) {
+      if (!isnan(U.v[k])) U.v[k] *= tmp_wind;
+      ra.v[k] = HUGE_RESIST;
+    }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------ soil thermal properties
+
+// soil_conduction.c:7-105 (Johansen)
+VIC_DEV double soil_conductivity(double moist, double Wu, double soil_dens_min, double bulk_dens_min, double quartz,
+                                 double soil_density, double bulk_density, double organic) {
+  const double Ki = 2.2, Kw = 0.57, Kdry_org = 0.05, Ks_org = 0.25;
+  double Kdry_min = (0.135 * bulk_dens_min + 64.7) / (soil_dens_min - 0.947 * bulk_dens_min);
+  double Kdry = (1 - organic) * Kdry_min + organic * Kdry_org;
+  double K;
+  if (moist > 0.) {
+    double porosity = 1.0 - bulk_density / soil_density;
+    double Sr = moist / porosity;
+    double Ks_min, Ks, Ksat, Ke;
+    if (quartz < .2) Ks_min = pow(7.7, quartz) * pow(3.0, 1.0 - quartz);
+    else Ks_min = pow(7.7, quartz) * pow(2.2, 1.0 - quartz);
+    Ks = (1 - organic) * Ks_min + organic * Ks_org;
+    if (Wu == moist) {
+      Ksat = pow(Ks, 1.0 - porosity) * pow(Kw, porosity);
+      Ke = 0.7 * log10(Sr) + 1.0;
+    } else {
+      Ksat = pow(Ks, 1.0 - porosity) * pow(Ki, porosity - Wu) * pow(Kw, Wu);
+      Ke = Sr;
+    }
+    K = (Ksat - Kdry) * Ke + Kdry;
+    if (K < Kdry) K = Kdry;
+  } else K = Kdry;
+  return K;
+}
+
+// soil_conduction.c:108-139
+VIC_DEV double volumetric_heat_capacity(double soil_fract, double water_fract, double ice_fract, double organic_fract) {
+  double Cs = 2.0e6 * soil_fract * (1 - organic_fract);
+  Cs += 2.7e6 * soil_fract * organic_fract;
+  Cs += 4.2e6 * water_fract;
+  Cs += 1.9e6 * ice_fract;
+  Cs += 1.3e3 * (1. - (soil_fract + water_fract + ice_fract));
+  return Cs;
+}
+
+// soil_conduction.c:830-863
+VIC_DEV double maximum_unfrozen_water(double T, double max_moist, double bubble, double expt) {
+  double u;
+  if (T <= 0) {
+    u = max_moist * pow((-LF * T) / 273.16 / (9.81 * bubble / 100.), -(2.0 / (expt - 3.0)));
+    if (u > max_moist) u = max_moist;
+    if (u < 0) u = 0;
+  } else u = max_moist;
+  return u;
+}
+
+VIC_DEV double linear_interp(double x, double lx, double ux, double ly, double uy) { return (x - lx) / (ux - lx) * (uy - ly) + ly; }
+
+}  // namespace vic

@@ -1,0 +1,396 @@
+// vic_step.hpp — one HRU step: full_energy's per-HRU body and surface_fluxes (device only, gfx950).
+#pragma once
+#include "vic_surface.hpp"
+
+namespace vic {
+
+struct SolveSnowOut {
+  double melt, Le, LongUnderIn, NetLongSnow, NetShortGrnd, NetShortSnow, ShortUnderIn, OldTSurf, delta_coverage, melt_energy,
+         out_prec, out_rain, out_snow, ppt, rainfall, snowfall;
+  bool ok;
+};
+
+// solve_snow (solve_snow.c:7-544), mu = 1, SPATIAL_SNOW off.  `coverage` and `surf_atten` persist across sub-steps in
+// the caller, UnderStory is in/out (NCASE = not yet decided).
+VIC_DEV SolveSnowOut solve_snow(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, int hidx,
+                                int veg_idx, const Dmy& dmy, bool overstory, bool is_artificial_bare, double BareAlbedo,
+                                double LongUnderOut, double Tcanopy, double Tgrnd, double air_temp, double prec, double& AlbedoUnder,
+                                const Vc& Ra, const Vc& U, const Vc& disp, const Vc& zref, const Vc& z0, double* ra_used,
+                                double& coverage, double& surf_atten, double& snow_inflow, int& UnderStory, int dt,
+                                const double* lmoist, const double* lice, const double* root, double* layerevap, Snow& snow,
+                                SnowEnergy& se, VegVar& vv) {
+  SolveSnowOut r;
+  r.ok = true; r.melt = 0.; r.ppt = 0.; r.melt_energy = 0.; r.OldTSurf = 0.; r.delta_coverage = 0.;
+  r.NetLongSnow = 0.; r.NetShortGrnd = 0.; r.NetShortSnow = 0.;
+  const int month = dmy.month;
+  const double rainonly = calc_rainonly(o, air_temp, prec, cv.s(CP_MAX_SNOW_TEMP), cv.s(CP_MIN_RAIN_TEMP));
+  double snowfall = 1.0 * (prec - rainonly) * cv.s(CP_PADJ_S);     // gauge correction = 1 (CORRPREC off)
+  double rainfall = 1.0 * rainonly * cv.s(CP_PADJ_R);
+  r.out_prec = snowfall + rainfall; r.out_rain = rainfall; r.out_snow = snowfall;
+  const double store_snowfall = snowfall;
+  r.Le = (2.501e6 - 0.002361e6 * air_temp);
+  if (UnderStory == NCASE) UnderStory = (snow.swq > 0 || snowfall > 0) ? SNOW_COVERED : SNOW_FREE;
+  r.ShortUnderIn = fc.v(VIC_F_SHORTWAVE, hidx);
+  r.LongUnderIn = fc.v(VIC_F_LONGWAVE, hidx);
+
+  if (snow.swq > 0 || snowfall > 0. || (snow.snow_canopy > 0. && overstory)) {
+    snow.snow = 1;
+    if (!overstory) surf_atten = 1.;
+    const double old_coverage = snow.coverage;
+    if (!is_artificial_bare) {
+      if (overstory) {
+        const VegMonth vm = veg_month(vl, veg_idx, month);
+        r.ShortUnderIn *= surf_atten;
+        const double ShortOverIn = (1. - surf_atten) * fc.v(VIC_F_SHORTWAVE, hidx);
+        if (!snow_intercept(o, cv, vm, s3, fc, hidx, (double)dt * SECPHOUR, r.Le, LongUnderOut, ShortOverIn, Tcanopy, BareAlbedo,
+                            Ra, U, disp, zref, z0, ra_used, rainfall, snowfall, r.LongUnderIn, lmoist, lice, root, layerevap, snow,
+                            se, vv))
+          r.ok = false;
+        vv.throughfall = rainfall + snowfall;
+        se.LongOverIn = fc.v(VIC_F_LONGWAVE, hidx);
+      } else if (snowfall > 0. && vv.Wdew > 0.) {
+        rainfall += vv.Wdew;
+        vv.throughfall = rainfall + snowfall;
+        vv.Wdew = 0.;
+        se.NetLongOver = 0; se.LongOverIn = 0; se.Tfoliage = air_temp; se.Tfoliage_fbflag = 0;
+      } else {
+        vv.throughfall = rainfall + snowfall;
+        se.NetLongOver = 0; se.LongOverIn = 0; se.Tfoliage = air_temp; se.Tfoliage_fbflag = 0;
+      }
+    } else { se.NetLongOver = 0; se.LongOverIn = 0; }
+
+    if (snow.swq > 0.0 || snowfall > 0) {
+      r.NetShortGrnd = 0.;
+      snow_inflow += rainfall + snowfall;
+      const double old_swq = snow.swq;
+      UnderStory = SNOW_COVERED;
+      if (snow.swq > 0 && store_snowfall == 0) {
+        snow.last_snow++;
+        snow.albedo = snow_albedo(o, cv, snowfall, snow.swq, snow.depth, snow.albedo, snow.coldcontent, (double)dt, snow.last_snow, snow.MELTING);
+        AlbedoUnder = (coverage * snow.albedo + (1. - coverage) * BareAlbedo);
+      } else {
+        snow.last_snow = 0;
+        snow.albedo = cv.s(CP_NEW_SNOW_ALB);
+        AlbedoUnder = snow.albedo;
+      }
+      r.NetShortSnow = (1.0 - AlbedoUnder) * (r.ShortUnderIn);
+      SnowMeltOut sm = snow_melt(o, r.Le, r.NetShortSnow, Tcanopy, Tgrnd, z0.v[SNOW_COVERED], Ra.v[SNOW_COVERED], ra_used[0], air_temp,
+                                 (double)dt * SECPHOUR, fc.v(VIC_F_DENSITY, hidx), r.LongUnderIn, fc.v(VIC_F_PRESSURE, hidx), rainfall,
+                                 snowfall, fc.v(VIC_F_VP, hidx), fc.v(VIC_F_VPD, hidx), U.v[SNOW_COVERED], zref.v[SNOW_COVERED], snow, se);
+      if (!sm.ok) r.ok = false;
+      r.melt = sm.melt; r.NetLongSnow = sm.NetLongSnow; r.OldTSurf = sm.OldTSurf;
+      r.ppt += r.melt;
+      if (snow.swq > 0.) {
+        if (!isnan(snow.surf_temp) && snow.surf_temp <= 0) snow.density = snow_density(o, snow, snowfall, old_swq, air_temp, (double)dt);
+        else if (snow.last_snow == 0) snow.density = new_snow_density(o, air_temp);
+        snow.depth = 1000. * snow.swq / snow.density;
+        const double lat = cv.s(CP_LAT);
+        if (snow.coldcontent >= 0 && ((lat >= 0 && (dmy.day_in_year > 60 && dmy.day_in_year < 273))
+                                      || (lat < 0 && (dmy.day_in_year < 60 || dmy.day_in_year > 273))))
+          snow.MELTING = 1;
+        else if (snow.MELTING && snowfall > TRACESNOW) snow.MELTING = 0;
+        snow.coverage = 1.;
+      } else snow.coverage = 0.;
+      r.delta_coverage = old_coverage - snow.coverage;
+      if (r.delta_coverage != 0) {
+        if (old_coverage > snow.coverage) {
+          coverage = old_coverage;
+          AlbedoUnder = (coverage - snow.coverage) / (1. - snow.coverage) * snow.albedo;
+          AlbedoUnder += (1. - coverage) / (1. - snow.coverage) * BareAlbedo;
+          r.melt_energy = (r.delta_coverage) * (se.advection - se.deltaCC + se.latent + se.latent_sub + se.sensible
+                                                + se.refreeze_energy + se.advected_sensible);
+        } else {
+          coverage = snow.coverage;
+          r.delta_coverage = 0;
+        }
+      } else if (old_coverage == 0 && snow.coverage == 0) {
+        r.delta_coverage = 1.;
+        coverage = 0.;
+        r.melt_energy = (se.advection - se.deltaCC + se.latent + se.latent_sub + se.sensible + se.refreeze_energy + se.advected_sensible);
+      }
+      r.NetLongSnow *= (snow.coverage);
+      r.NetShortSnow *= (snow.coverage);
+      r.NetShortGrnd *= (snow.coverage);
+      se.latent *= (snow.coverage + r.delta_coverage);
+      se.latent_sub *= (snow.coverage + r.delta_coverage);
+      se.sensible *= (snow.coverage + r.delta_coverage);
+      if (snow.swq == 0) {
+        snow.density = 0.; snow.depth = 0.; snow.surf_water = 0; snow.pack_water = 0; snow.surf_temp = 0; snow.pack_temp = 0;
+        snow.coverage = 0; snow.swq_slope = 0; snow.store_snow = 1; snow.MELTING = 0;
+      }
+      snowfall = 0;
+      rainfall = 0;
+    } else {
+      r.ppt += rainfall;
+      se.AlbedoOver = 0.;
+      AlbedoUnder = BareAlbedo;
+      r.NetLongSnow = 0.; r.NetShortSnow = 0.; r.NetShortGrnd = 0.; r.delta_coverage = 0.;
+      se.latent = 0.; se.latent_sub = 0.; se.sensible = 0.;
+      snow.last_snow = INVALID_INT;
+      snow.store_swq = 0; snow.store_coverage = 1; snow.MELTING = 0;
+    }
+  } else {
+    UnderStory = SNOW_FREE;
+    snow.snow = 0;
+    se.AlbedoOver = 0.;
+    AlbedoUnder = BareAlbedo;
+    se.NetLongOver = 0.; se.LongOverIn = 0.; se.NetShortOver = 0.; se.ShortOverIn = 0.;
+    se.latent = 0.; se.latent_sub = 0.; se.sensible = 0.;
+    r.NetLongSnow = 0.; r.NetShortSnow = 0.; r.NetShortGrnd = 0.; r.delta_coverage = 0.;
+    se.Tfoliage = Tcanopy;
+    snow.store_swq = 0; snow.store_coverage = 1; snow.MELTING = 0; snow.last_snow = INVALID_INT;
+    snow.albedo = cv.s(CP_NEW_SNOW_ALB);
+  }
+  r.rainfall = rainfall; r.snowfall = snowfall;
+  return r;
+}
+
+// Everything one HRU carries through a step (loaded from / stored to the SoA state tables by the kernel)
+template <int NN>
+struct HruWork {
+  double moist[3], ice[3], layer_T[3], evap[3];
+  Nodes<NN> nd;
+  Snow snow;
+  VegVar vv;
+  SnowEnergy se;
+  SoilEnergy so;
+  // sticky diagnostics that belong to neither side exclusively
+  double Tcanopy;
+  // per-step outputs
+  double runoff, baseflow, asat, inflow, pot_evap[NPET], aero_resist_surface, aero_resist_overstory, rootmoist, wetness;
+  Zwt zwt;
+  double AtmosLatent, AtmosLatentSub, AtmosSensible, LongUnderIn, NetLongAtmos, NetShortAtmos, ShortUnderIn_avg, AlbedoOver_avg,
+         AlbedoUnder_avg, LongOverIn_avg, NetLongOver_avg, NetShortOver_avg, ShortOverIn_avg;
+  double out_prec, out_rain, out_snow;
+};
+
+// surface_fluxes (surface_fluxes.c:17-956) with CLOSE_ENERGY FALSE (both closure loops execute once), Ndist 1.
+// The reference's iter_* / step_* struct copies collapse to in-place updates of the snow side (se, snow, vv_snow) and
+// the soil side (so, nodes, layers, vv_soil); both sides start from last step's values as surface_fluxes.c:301-323 does.
+template <int NN>
+VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, const Dmy& dmy,
+                            int veg_idx, int band, bool is_artificial_bare, bool overstory, double BareAlbedo, double ice0,
+                            double moist0, double surf_atten, const Vc* aero_pet_under_free, const Vc& Ra, const Vc& U,
+                            const Vc& disp, const Vc& zref, const Vc& z0, const double* root, HruWork<NN>& w) {
+  // aero_pet_under_free[p].v = { snowFree, canopy, snowCovered, - } resistances of PET type p (full_energy.c:302-354)
+  const int NF = o.NF, NR = o.NR;
+  Snow& snow = w.snow;
+  SnowEnergy& se = w.se;
+  SoilEnergy& so = w.so;
+  bool ok = true;
+
+  so.advection = 0; so.deltaCC = 0; so.refreeze_energy = 0;           // energy->advection / deltaCC / refreeze_energy = 0
+  se.advection = 0; se.deltaCC = 0; se.refreeze_energy = 0;
+  double snow_flux = (snow.swq > 0) ? so.snow_flux : -(so.grnd_flux + so.deltaH + so.fusion);
+  double coverage = snow.coverage;
+  VegVar vv_snow = w.vv, vv_soil = w.vv;
+  vv_snow.canopyevap = 0; vv_soil.canopyevap = 0; vv_snow.throughfall = 0; vv_soil.throughfall = 0;
+  w.evap[0] = w.evap[1] = w.evap[2] = 0;
+
+  int hidx, endhidx, step_dt;
+  if (snow.swq > 0 || snow.snow_canopy > 0 || fc.flag(NR)) { hidx = 0; endhidx = NF; step_dt = o.snow_step; }
+  else { hidx = NR; endhidx = NR + 1; step_dt = o.dt; }
+
+  double last_snow_coverage = snow.coverage;
+  const double Tgrnd0 = w.nd.T[0];   // Tgrnd = energy->T[0] reads the CALLER's struct (surface_fluxes.c:423): start-of-step value
+  double step_Wdew = w.vv.Wdew;
+  double AlbedoUnder_orig = so.AlbedoUnder;     // &energy->AlbedoUnder of the caller's struct (solve_snow's AlbedoUnder argument)
+  double snow_inflow = 0;
+  int INCLUDE_SNOW = 0, N_steps = 0;
+  double delta_coverage = 0;
+
+  double st_AlbedoOver = 0, st_AlbedoUnder = 0, st_AtmosLatent = 0, st_AtmosLatentSub = 0, st_AtmosSensible = 0, st_LongOverIn = 0,
+         st_LongUnderIn = 0, st_LongUnderOut = 0, st_NetLongAtmos = 0, st_NetLongOver = 0, st_NetLongUnder = 0, st_NetShortAtmos = 0,
+         st_NetShortGrnd = 0, st_NetShortOver = 0, st_NetShortUnder = 0, st_ShortOverIn = 0, st_ShortUnderIn = 0,
+         st_advected_sensible = 0, st_advection = 0, st_canopy_advection = 0, st_canopy_latent = 0, st_canopy_latent_sub = 0,
+         st_canopy_sensible = 0, st_canopy_refreeze = 0, st_deltaCC = 0, st_deltaH = 0, st_fusion = 0, st_grnd_flux = 0,
+         st_latent = 0, st_latent_sub = 0, st_melt_energy = 0, st_refreeze_energy = 0, st_sensible = 0, st_snow_flux = 0,
+         st_canopy_vapor_flux = 0, st_melt = 0, st_vapor_flux = 0, st_blowing_flux = 0, st_surface_flux = 0, st_canopyevap = 0,
+         st_throughfall = 0, st_ppt = 0, st_cond_surface = 0, st_cond_overstory = 0;
+  double st_layerevap[3] = {0, 0, 0}, st_pot_evap[NPET] = {0, 0, 0, 0, 0, 0};
+  const double ShortUnderIn_soil = 0;   // soil_energy.ShortUnderIn is never assigned for non-glacier HRUs: it keeps the 0 of
+                                        // initialize_model_state.c:278 through surface_fluxes.c:781,859
+  w.out_prec = w.out_rain = w.out_snow = 0;
+
+  do {
+    const double Tair = fc.v(VIC_F_AIR_TEMP, hidx) + cv.band(CPB_TFACTOR, band);
+    const double step_prec = fc.v(VIC_F_PREC, hidx) / 1.0 * cv.band(CPB_PFACTOR, band);
+    const double Tcanopy = Tair;
+    const double VPcanopy = fc.v(VIC_F_VP, hidx), VPDcanopy = fc.v(VIC_F_VPD, hidx);
+    snow.blowing_flux = 0.0;
+    int UnderStory = NCASE;
+    const double snow_grnd_flux = -snow_flux;
+    (void)snow_grnd_flux;                     // overwritten inside snow_melt
+    // per-iteration resets (surface_fluxes.c:501-532)
+    vv_snow.Wdew = step_Wdew; vv_soil.Wdew = step_Wdew;
+    vv_snow.canopyevap = 0; vv_soil.canopyevap = 0;
+    double layerevap[3] = {0, 0, 0};
+    double ra_used[2] = {w.aero_resist_surface, w.aero_resist_overstory};
+    snow.canopy_vapor_flux = 0; snow.vapor_flux = 0; snow.surface_flux = 0;
+    const double LongUnderOut = so.LongUnderOut;
+    const double step_snow_surf_temp = snow.surf_temp, step_snow_depth = snow.depth;
+
+    SolveSnowOut ss = solve_snow(o, cv, vl, s3, fc, hidx, veg_idx, dmy, overstory, is_artificial_bare, BareAlbedo, LongUnderOut,
+                                 Tcanopy, Tgrnd0, Tair, step_prec, AlbedoUnder_orig, Ra, U, disp, zref, z0, ra_used, coverage,
+                                 surf_atten, snow_inflow, UnderStory, step_dt, w.moist, w.ice, root, layerevap, snow, se, vv_snow);
+    if (!ss.ok) ok = false;
+    delta_coverage = ss.delta_coverage;
+    double step_melt = ss.melt, step_melt_energy = ss.melt_energy, step_ppt = ss.ppt;
+
+    if (isnan(snow.surf_temp) && snow.swq > 0) {                       // surface_fluxes.c:553-560 (UNSTABLE_SNOW is never set)
+      INCLUDE_SNOW = UnderStory + 1;
+      so.advection = se.advection;
+      snow.surf_temp = step_snow_surf_temp;
+      step_melt_energy = 0;
+    } else INCLUDE_SNOW = 0;
+
+    SurfOut sf = calc_surf_energy_bal<NN>(o, cv, vl, s3, fc, hidx, veg_idx, dmy.month, is_artificial_bare, overstory, ss.Le,
+                                          ss.LongUnderIn, ss.NetLongSnow, ss.NetShortGrnd, ss.NetShortSnow, ss.OldTSurf, ss.ShortUnderIn,
+                                          snow.albedo, se.latent, se.latent_sub, se.sensible, Tcanopy, VPDcanopy, VPcanopy,
+                                          delta_coverage, ice0, step_melt_energy, moist0, snow.coverage,
+                                          (step_snow_depth + snow.depth) / 2., BareAlbedo, surf_atten, Ra, U, disp, zref, z0, ra_used,
+                                          step_melt, step_ppt, ss.rainfall, root, INCLUDE_SNOW, UnderStory, step_dt, w.moist, w.ice,
+                                          w.layer_T, layerevap, w.nd, so, snow, vv_soil);
+    if (!sf.ok) ok = false;
+    step_melt = sf.melt; step_ppt = sf.ppt;
+    if (INCLUDE_SNOW) step_ppt += step_melt;
+
+    const double AtmosLatent = so.latent, AtmosLatentSub = so.latent_sub, AtmosSensible = so.sensible;
+    const double NetLongAtmos = so.NetLongUnder, NetShortAtmos = so.NetShortUnder;
+    w.Tcanopy = Tcanopy;
+
+    // potential evaporation, surface_fluxes.c:658-693
+    double stability_factor[2], ra_s[NPET], ra_o[NPET], pe[NPET];
+    if (ra_used[0] == HUGE_RESIST) stability_factor[0] = HUGE_RESIST;
+    else stability_factor[0] = ra_used[0] / Ra.v[UnderStory];
+    if (ra_used[1] == ra_used[0]) stability_factor[1] = stability_factor[0];
+    else if (ra_used[1] == HUGE_RESIST) stability_factor[1] = HUGE_RESIST;
+    else stability_factor[1] = ra_used[1] / Ra.v[CANOPY];
+#pragma unroll
+    for (int p = 0; p < NPET; p++) {
+      ra_s[p] = (stability_factor[0] == HUGE_RESIST) ? HUGE_RESIST : aero_pet_under_free[p].v[UnderStory] * stability_factor[0];
+      ra_o[p] = (stability_factor[1] == HUGE_RESIST) ? HUGE_RESIST : aero_pet_under_free[p].v[CANOPY] * stability_factor[1];
+    }
+    compute_pot_evap(o, vl, veg_idx, dmy.month, fc.v(VIC_F_SHORTWAVE, hidx), NetLongAtmos, Tair, VPDcanopy, cv.s(CP_ELEVATION), ra_s,
+                     ra_o, pe);
+
+    // store sub-step, surface_fluxes.c:699-816
+    if (!is_artificial_bare) {
+      if (snow.snow) { st_throughfall += vv_snow.throughfall; st_canopyevap += vv_snow.canopyevap; vv_soil.Wdew = vv_snow.Wdew; }
+      else { st_throughfall += vv_soil.throughfall; st_canopyevap += vv_soil.canopyevap; vv_snow.Wdew = vv_soil.Wdew; }
+      step_Wdew = vv_soil.Wdew;
+    }
+#pragma unroll
+    for (int l = 0; l < 3; l++) st_layerevap[l] += layerevap[l];
+    st_ppt += step_ppt;
+    st_cond_surface += (ra_used[0] > 0) ? 1 / ra_used[0] : HUGE_RESIST;
+    st_cond_overstory += (ra_used[1] > 0) ? 1 / ra_used[1] : HUGE_RESIST;
+    if (!is_artificial_bare) st_canopy_vapor_flux += snow.canopy_vapor_flux;
+    st_melt += step_melt;
+    st_vapor_flux += snow.vapor_flux;
+    st_surface_flux += snow.surface_flux;
+    st_blowing_flux += snow.blowing_flux;
+    w.out_prec += ss.out_prec * 1.0; w.out_rain += ss.out_rain * 1.0; w.out_snow += ss.out_snow * 1.0;
+    if (INCLUDE_SNOW) {
+      se.advected_sensible = so.advected_sensible;   // never written on the soil side: last step's average
+      se.advection = so.advection; se.deltaCC = so.deltaCC; se.latent = so.latent; se.latent_sub = so.latent_sub;
+      se.refreeze_energy = so.refreeze_energy; se.sensible = so.sensible; se.snow_flux = so.snow_flux;
+    }
+    st_AlbedoOver += se.AlbedoOver;
+    st_AlbedoUnder += so.AlbedoUnder;
+    st_AtmosLatent += AtmosLatent; st_AtmosLatentSub += AtmosLatentSub; st_AtmosSensible += AtmosSensible;
+    st_LongOverIn += se.LongOverIn;
+    st_LongUnderIn += ss.LongUnderIn;
+    st_LongUnderOut += so.LongUnderOut;
+    st_NetLongAtmos += NetLongAtmos;
+    st_NetLongOver += se.NetLongOver;
+    st_NetLongUnder += so.NetLongUnder;
+    st_NetShortAtmos += NetShortAtmos;
+    st_NetShortGrnd += ss.NetShortGrnd;
+    st_NetShortOver += se.NetShortOver;
+    st_NetShortUnder += so.NetShortUnder;
+    st_ShortOverIn += se.ShortOverIn;
+    st_ShortUnderIn += ShortUnderIn_soil;
+    st_canopy_advection += se.canopy_advection; st_canopy_latent += se.canopy_latent; st_canopy_latent_sub += se.canopy_latent_sub;
+    st_canopy_sensible += se.canopy_sensible; st_canopy_refreeze += se.canopy_refreeze;
+    st_deltaH += so.deltaH; st_fusion += so.fusion; st_grnd_flux += so.grnd_flux; st_latent += so.latent;
+    st_latent_sub += so.latent_sub; st_melt_energy += step_melt_energy; st_sensible += so.sensible;
+    if (snow.swq == 0 && INCLUDE_SNOW) {
+      if (last_snow_coverage == 0) last_snow_coverage = 1;             // pointer test always true, SURVEY.md Appendix C #5
+      st_advected_sensible += se.advected_sensible * last_snow_coverage;
+      st_advection += se.advection * last_snow_coverage;
+      st_deltaCC += se.deltaCC * last_snow_coverage;
+      st_snow_flux += so.snow_flux * last_snow_coverage;
+      st_refreeze_energy += se.refreeze_energy * last_snow_coverage;
+    } else if (snow.snow || INCLUDE_SNOW) {
+      const double cf = (snow.coverage + delta_coverage);
+      st_advected_sensible += se.advected_sensible * cf;
+      st_advection += se.advection * cf;
+      st_deltaCC += se.deltaCC * cf;
+      st_snow_flux += so.snow_flux * cf;
+      st_refreeze_energy += se.refreeze_energy * cf;
+    }
+#pragma unroll
+    for (int p = 0; p < NPET; p++) st_pot_evap[p] += pe[p];
+    N_steps++;
+    hidx += 1;
+  } while (hidx < endhidx);
+
+  const double N = (double)N_steps;
+  snow.vapor_flux = st_vapor_flux; snow.blowing_flux = st_blowing_flux; snow.surface_flux = st_surface_flux;
+  snow.canopy_vapor_flux = st_canopy_vapor_flux; snow.melt = st_melt;
+  double ppt = st_ppt;
+
+  // *energy = soil_energy, then the step averages (surface_fluxes.c:842-881)
+  w.AlbedoOver_avg = st_AlbedoOver / N;
+  so.AlbedoUnder = st_AlbedoUnder / N;
+  w.AtmosLatent = st_AtmosLatent / N; w.AtmosLatentSub = st_AtmosLatentSub / N; w.AtmosSensible = st_AtmosSensible / N;
+  w.LongOverIn_avg = st_LongOverIn / N;
+  w.LongUnderIn = st_LongUnderIn / N;
+  so.LongUnderOut = st_LongUnderOut / N;
+  w.NetLongAtmos = st_NetLongAtmos / N;
+  w.NetLongOver_avg = st_NetLongOver / N;
+  so.NetLongUnder = st_NetLongUnder / N;
+  w.NetShortAtmos = st_NetShortAtmos / N;
+  so.NetShortGrnd = st_NetShortGrnd / N;
+  w.NetShortOver_avg = st_NetShortOver / N;
+  so.NetShortUnder = st_NetShortUnder / N;
+  w.ShortOverIn_avg = st_ShortOverIn / N;
+  w.ShortUnderIn_avg = st_ShortUnderIn / N;
+  so.advected_sensible = st_advected_sensible / N;
+  se.canopy_advection = st_canopy_advection / N; se.canopy_latent = st_canopy_latent / N;
+  se.canopy_latent_sub = st_canopy_latent_sub / N; se.canopy_refreeze = st_canopy_refreeze / N;
+  se.canopy_sensible = st_canopy_sensible / N;
+  so.deltaH = st_deltaH / N; so.fusion = st_fusion / N; so.grnd_flux = st_grnd_flux / N; so.latent = st_latent / N;
+  so.latent_sub = st_latent_sub / N; so.melt_energy = st_melt_energy / N; so.sensible = st_sensible / N;
+  if (snow.snow || INCLUDE_SNOW) {
+    so.advection = st_advection / N; so.deltaCC = st_deltaCC / N; so.refreeze_energy = st_refreeze_energy / N;
+    so.snow_flux = st_snow_flux / N;
+  }
+
+  if (!is_artificial_bare) {
+    w.vv.throughfall = st_throughfall;
+    w.vv.canopyevap = st_canopyevap;
+    w.vv.Wdew = snow.snow ? vv_snow.Wdew : vv_soil.Wdew;
+  }
+#pragma unroll
+  for (int l = 0; l < 3; l++) w.evap[l] = st_layerevap[l];
+  if (st_cond_surface > 0 && st_cond_surface < HUGE_RESIST) w.aero_resist_surface = 1 / (st_cond_surface / N);
+  else if (st_cond_surface >= HUGE_RESIST) w.aero_resist_surface = 0;
+  else w.aero_resist_surface = HUGE_RESIST;
+  if (st_cond_overstory > 0 && st_cond_overstory < HUGE_RESIST) w.aero_resist_overstory = 1 / (st_cond_overstory / N);
+  else if (st_cond_overstory >= HUGE_RESIST) w.aero_resist_overstory = 0;
+  else w.aero_resist_overstory = HUGE_RESIST;
+#pragma unroll
+  for (int p = 0; p < NPET; p++) w.pot_evap[p] = st_pot_evap[p] / N;
+
+  // runoff, surface_fluxes.c:941-948 (excess_moist is 0 after initialisation)
+  w.inflow = ppt;
+  RunoffOut ro = runoff_step(o, cv, s3, w.moist, w.ice, w.evap, ppt);
+  w.runoff = ro.runoff; w.baseflow = ro.baseflow; w.asat = ro.asat;
+  w.zwt = wrap_compute_zwt(cv, s3, w.moist);
+  if (o.FULL_ENERGY || o.FROZEN_SOIL) distribute_node_moisture_properties<NN>(o, cv, s3, w.nd, w.moist);
+  return ok;
+}
+
+}  // namespace vic

@@ -1,0 +1,680 @@
+// vicgpu_api.hip — C-ABI of the MI355X VIC hot path (include/vicgpu.h) and its kernels.  gfx950 only.
+//
+// Kernels
+//   vic_hru_step<NN>   one lane per HRU: the per-HRU body of full_energy (full_energy.c:216-456) = aerodynamics,
+//                      prepare_full_energy, surface_fluxes (snow, ground energy balance, pot. evap), runoff.
+//                      HBM-side it is a streaming read-modify-write of the SoA state table; all physics is fp64 VALU.
+//   vic_cell_reduce    one lane per cell: atmos->out_prec/out_rain/out_snow (full_energy.c:429-431) summed in hruList
+//                      order (deterministic, no atomics) and the Cv-weighted per-cell accumulators.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "vicgpu.h"
+#include "vic_step.hpp"
+
+using namespace vic;
+
+#define HIPIGN(call) do { hipError_t ign_ = (call); (void)ign_; } while (0)
+#define HIPCHK(ctx, call)                                                                              \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                  \
+      return VICGPU_ERR_HIP;                                                                           \
+    }                                                                                                  \
+  } while (0)
+
+struct KArgs {
+  Opt o;
+  int ncell, nhru, nveg_rows, write_fluxes;
+  const double* veglib;
+  const double* cell_params;
+  const int* hpi;
+  const double* hpd;
+  const double* forcing;            // this step: [VIC_NFORCE][NF+1][ncell]
+  const unsigned char* snowflag;    // this step: [NF+1][ncell]
+  Dmy dmy;
+  double* sd;
+  int* si;
+  double* flux;
+  int* hru_err;                     // [nhru]
+};
+
+// ------------------------------------------------------------------------------------------------ state table I/O
+template <int NN>
+VIC_DEV void load_state(const KArgs& a, int g, HruWork<NN>& w) {
+  const int Nn = a.o.Nnode;
+  const size_t nh = a.nhru;
+  const double* __restrict__ sd = a.sd;
+  const int* __restrict__ si = a.si;
+#define SD(row) sd[(size_t)(row) * nh + g]
+#define SI(row) si[(size_t)(row) * nh + g]
+#pragma unroll
+  for (int l = 0; l < 3; l++) { w.moist[l] = SD(SD_MOIST0 + l); w.ice[l] = SD(SD_ICE0 + l); w.layer_T[l] = SD(SD_LAYER_T0 + l); w.evap[l] = 0; }
+  SoilEnergy& so = w.so; SnowEnergy& se = w.se; Snow& s = w.snow;
+  so.snow_flux = SD(SD_SNOW_FLUX); so.grnd_flux = SD(SD_GRND_FLUX); so.deltaH = SD(SD_DELTAH); so.fusion = SD(SD_FUSION);
+  so.LongUnderOut = SD(SD_LONGUNDEROUT); se.Tfoliage = SD(SD_TFOLIAGE);
+  s.albedo = SD(SD_SNOW_ALBEDO); s.coldcontent = SD(SD_SNOW_COLDCONTENT); s.coverage = SD(SD_SNOW_COVERAGE);
+  s.density = SD(SD_SNOW_DENSITY); s.depth = SD(SD_SNOW_DEPTH); s.pack_temp = SD(SD_SNOW_PACK_TEMP);
+  s.pack_water = SD(SD_SNOW_PACK_WATER); s.snow_canopy = SD(SD_SNOW_CANOPY); s.surf_temp = SD(SD_SNOW_SURF_TEMP);
+  s.surf_water = SD(SD_SNOW_SURF_WATER); s.swq = SD(SD_SNOW_SWQ); s.tmp_int_storage = SD(SD_SNOW_TMP_INT_STORAGE);
+  s.store_swq = SD(SD_SNOW_STORE_SWQ); s.store_coverage = SD(SD_SNOW_STORE_COVERAGE); s.swq_slope = SD(SD_SNOW_SWQ_SLOPE);
+  s.max_swq = SD(SD_SNOW_MAX_SWQ);
+  s.blowing_flux = 0; s.canopy_vapor_flux = 0; s.mass_error = 0; s.melt = 0; s.Qnet = 0; s.surface_flux = 0; s.vapor_flux = 0;
+  w.vv.Wdew = SD(SD_WDEW); w.vv.canopyevap = 0; w.vv.throughfall = 0;
+  w.Tcanopy = SD(SD_TCANOPY); so.Tsurf = SD(SD_TSURF); se.AlbedoOver = SD(SD_ALBEDO_OVER); so.AlbedoUnder = SD(SD_ALBEDO_UNDER);
+  se.canopy_advection = SD(SD_CANOPY_ADVECTION); se.canopy_latent = SD(SD_CANOPY_LATENT);
+  se.canopy_latent_sub = SD(SD_CANOPY_LATENT_SUB); se.canopy_sensible = SD(SD_CANOPY_SENSIBLE);
+  se.canopy_refreeze = SD(SD_CANOPY_REFREEZE);
+  se.advected_sensible = so.advected_sensible = SD(SD_ADVECTED_SENSIBLE);
+  se.advection = so.advection = SD(SD_ADVECTION);
+  se.deltaCC = so.deltaCC = SD(SD_DELTACC);
+  se.refreeze_energy = so.refreeze_energy = SD(SD_REFREEZE_ENERGY);
+  so.melt_energy = SD(SD_MELT_ENERGY);
+  se.error = so.error = SD(SD_ERROR);
+  se.latent = so.latent = SD(SD_LATENT); se.latent_sub = so.latent_sub = SD(SD_LATENT_SUB);
+  se.sensible = so.sensible = SD(SD_SENSIBLE);
+  se.snow_flux = so.snow_flux;
+  se.LongOverIn = SD(SD_LONGOVERIN); se.NetLongOver = SD(SD_NETLONGOVER); se.NetShortOver = SD(SD_NETSHORTOVER);
+  se.ShortOverIn = SD(SD_SHORTOVERIN);
+  so.NetShortGrnd = 0; so.NetLongUnder = 0; so.NetShortUnder = 0;
+  so.kappa[0] = so.kappa[1] = so.Cs[0] = so.Cs[1] = 0;
+#pragma unroll
+  for (int f = 0; f < 3; f++) { so.fdepth[f] = 0; so.tdepth[f] = 0; }
+#pragma unroll
+  for (int n = 0; n < NN; n++) {
+    if (n < Nn) {
+      w.nd.T[n] = SD(VICGPU_SD_NODE(SDN_T, n, Nn)); w.nd.moist[n] = SD(VICGPU_SD_NODE(SDN_MOIST, n, Nn));
+      w.nd.ice[n] = SD(VICGPU_SD_NODE(SDN_ICE, n, Nn)); w.nd.kappa[n] = SD(VICGPU_SD_NODE(SDN_KAPPA, n, Nn));
+      w.nd.Cs[n] = SD(VICGPU_SD_NODE(SDN_CS, n, Nn));
+      w.nd.fbflag[n] = SI(VICGPU_SI_NODE(SIN_T_FBFLAG, n, Nn)); w.nd.fbcount[n] = SI(VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn));
+    } else {
+      w.nd.T[n] = 0; w.nd.moist[n] = 0; w.nd.ice[n] = 0; w.nd.kappa[n] = 0; w.nd.Cs[n] = 0; w.nd.fbflag[n] = 0; w.nd.fbcount[n] = 0;
+    }
+  }
+  s.last_snow = SI(SI_SNOW_LAST_SNOW); s.MELTING = SI(SI_SNOW_MELTING); s.snow = SI(SI_SNOW_SNOW); s.store_snow = SI(SI_SNOW_STORE_SNOW);
+  s.surf_temp_fbcount = SI(SI_SNOW_SURF_TEMP_FBCOUNT); s.surf_temp_fbflag = SI(SI_SNOW_SURF_TEMP_FBFLAG);
+  so.Tsurf_fbcount = SI(SI_TSURF_FBCOUNT); so.Tsurf_fbflag = SI(SI_TSURF_FBFLAG);
+  se.Tfoliage_fbcount = SI(SI_TFOLIAGE_FBCOUNT); se.Tfoliage_fbflag = SI(SI_TFOLIAGE_FBFLAG);
+  so.frozen = SI(SI_FROZEN); so.Nfrost = SI(SI_NFROST); so.Nthaw = SI(SI_NTHAW);
+#undef SD
+#undef SI
+}
+
+template <int NN>
+VIC_DEV void store_state(const KArgs& a, int g, const HruWork<NN>& w) {
+  const int Nn = a.o.Nnode;
+  const size_t nh = a.nhru;
+  double* __restrict__ sd = a.sd;
+  int* __restrict__ si = a.si;
+#define SD(row) sd[(size_t)(row) * nh + g]
+#define SI(row) si[(size_t)(row) * nh + g]
+#pragma unroll
+  for (int l = 0; l < 3; l++) { SD(SD_MOIST0 + l) = w.moist[l]; SD(SD_ICE0 + l) = w.ice[l]; SD(SD_LAYER_T0 + l) = w.layer_T[l]; }
+  const SoilEnergy& so = w.so; const SnowEnergy& se = w.se; const Snow& s = w.snow;
+  SD(SD_SNOW_FLUX) = so.snow_flux; SD(SD_GRND_FLUX) = so.grnd_flux; SD(SD_DELTAH) = so.deltaH; SD(SD_FUSION) = so.fusion;
+  SD(SD_LONGUNDEROUT) = so.LongUnderOut; SD(SD_TFOLIAGE) = se.Tfoliage;
+  SD(SD_SNOW_ALBEDO) = s.albedo; SD(SD_SNOW_COLDCONTENT) = s.coldcontent; SD(SD_SNOW_COVERAGE) = s.coverage;
+  SD(SD_SNOW_DENSITY) = s.density; SD(SD_SNOW_DEPTH) = s.depth; SD(SD_SNOW_PACK_TEMP) = s.pack_temp;
+  SD(SD_SNOW_PACK_WATER) = s.pack_water; SD(SD_SNOW_CANOPY) = s.snow_canopy; SD(SD_SNOW_SURF_TEMP) = s.surf_temp;
+  SD(SD_SNOW_SURF_WATER) = s.surf_water; SD(SD_SNOW_SWQ) = s.swq; SD(SD_SNOW_TMP_INT_STORAGE) = s.tmp_int_storage;
+  SD(SD_SNOW_STORE_SWQ) = s.store_swq; SD(SD_SNOW_STORE_COVERAGE) = s.store_coverage; SD(SD_SNOW_SWQ_SLOPE) = s.swq_slope;
+  SD(SD_SNOW_MAX_SWQ) = s.max_swq; SD(SD_WDEW) = w.vv.Wdew;
+  SD(SD_TCANOPY) = w.Tcanopy; SD(SD_TSURF) = so.Tsurf; SD(SD_ALBEDO_OVER) = w.AlbedoOver_avg; SD(SD_ALBEDO_UNDER) = so.AlbedoUnder;
+  SD(SD_CANOPY_ADVECTION) = se.canopy_advection; SD(SD_CANOPY_LATENT) = se.canopy_latent;
+  SD(SD_CANOPY_LATENT_SUB) = se.canopy_latent_sub; SD(SD_CANOPY_SENSIBLE) = se.canopy_sensible;
+  SD(SD_CANOPY_REFREEZE) = se.canopy_refreeze; SD(SD_ADVECTED_SENSIBLE) = so.advected_sensible;
+  SD(SD_ADVECTION) = so.advection; SD(SD_DELTACC) = so.deltaCC; SD(SD_REFREEZE_ENERGY) = so.refreeze_energy;
+  SD(SD_MELT_ENERGY) = so.melt_energy; SD(SD_ERROR) = so.error; SD(SD_LATENT) = so.latent; SD(SD_LATENT_SUB) = so.latent_sub;
+  SD(SD_SENSIBLE) = so.sensible; SD(SD_LONGOVERIN) = w.LongOverIn_avg; SD(SD_NETLONGOVER) = w.NetLongOver_avg;
+  SD(SD_NETSHORTOVER) = w.NetShortOver_avg; SD(SD_SHORTOVERIN) = w.ShortOverIn_avg;
+#pragma unroll
+  for (int n = 0; n < NN; n++) {
+    if (n < Nn) {
+      SD(VICGPU_SD_NODE(SDN_T, n, Nn)) = w.nd.T[n]; SD(VICGPU_SD_NODE(SDN_MOIST, n, Nn)) = w.nd.moist[n];
+      SD(VICGPU_SD_NODE(SDN_ICE, n, Nn)) = w.nd.ice[n]; SD(VICGPU_SD_NODE(SDN_KAPPA, n, Nn)) = w.nd.kappa[n];
+      SD(VICGPU_SD_NODE(SDN_CS, n, Nn)) = w.nd.Cs[n];
+      SI(VICGPU_SI_NODE(SIN_T_FBFLAG, n, Nn)) = w.nd.fbflag[n]; SI(VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn)) = w.nd.fbcount[n];
+    }
+  }
+  SI(SI_SNOW_LAST_SNOW) = s.last_snow; SI(SI_SNOW_MELTING) = s.MELTING; SI(SI_SNOW_SNOW) = s.snow; SI(SI_SNOW_STORE_SNOW) = s.store_snow;
+  SI(SI_SNOW_SURF_TEMP_FBCOUNT) = s.surf_temp_fbcount; SI(SI_SNOW_SURF_TEMP_FBFLAG) = s.surf_temp_fbflag;
+  SI(SI_TSURF_FBCOUNT) = so.Tsurf_fbcount; SI(SI_TSURF_FBFLAG) = so.Tsurf_fbflag;
+  SI(SI_TFOLIAGE_FBCOUNT) = se.Tfoliage_fbcount; SI(SI_TFOLIAGE_FBFLAG) = se.Tfoliage_fbflag;
+  SI(SI_FROZEN) = so.frozen; SI(SI_NFROST) = so.Nfrost; SI(SI_NTHAW) = so.Nthaw;
+#undef SD
+#undef SI
+}
+
+template <int NN>
+VIC_DEV void store_flux(const KArgs& a, int g, const HruWork<NN>& w) {
+  const size_t nh = a.nhru;
+  double* __restrict__ fx = a.flux;
+#define FX(row) fx[(size_t)(row) * nh + g]
+  // the three per-HRU precipitation terms are always written: vic_cell_reduce consumes them
+  FX(FX_OUT_PREC) = w.out_prec; FX(FX_OUT_RAIN) = w.out_rain; FX(FX_OUT_SNOW) = w.out_snow;
+  FX(FX_RUNOFF) = w.runoff; FX(FX_BASEFLOW) = w.baseflow;
+  FX(FX_EVAP0) = w.evap[0]; FX(FX_EVAP1) = w.evap[1]; FX(FX_EVAP2) = w.evap[2];
+  FX(FX_CANOPYEVAP) = w.vv.canopyevap; FX(FX_SNOW_VAPOR_FLUX) = w.snow.vapor_flux;
+  FX(FX_SNOW_CANOPY_VAPOR_FLUX) = w.snow.canopy_vapor_flux;
+  if (!a.write_fluxes) return;
+  FX(FX_ASAT) = w.asat; FX(FX_INFLOW) = w.inflow; FX(FX_THROUGHFALL) = w.vv.throughfall;
+  FX(FX_SNOW_BLOWING_FLUX) = w.snow.blowing_flux; FX(FX_SNOW_SURFACE_FLUX) = w.snow.surface_flux; FX(FX_SNOW_MELT) = w.snow.melt;
+  FX(FX_SNOW_MASS_ERROR) = w.snow.mass_error; FX(FX_SNOW_QNET) = w.snow.Qnet;
+#pragma unroll
+  for (int p = 0; p < NPET; p++) FX(FX_POT_EVAP0 + p) = w.pot_evap[p];
+  FX(FX_AERO_RESIST_SURFACE) = w.aero_resist_surface; FX(FX_AERO_RESIST_OVERSTORY) = w.aero_resist_overstory;
+  FX(FX_ROOTMOIST) = w.rootmoist; FX(FX_WETNESS) = w.wetness;
+  FX(FX_ZWT) = w.zwt.zwt; FX(FX_ZWT2) = w.zwt.zwt2; FX(FX_ZWT3) = w.zwt.zwt3;
+  FX(FX_ATMOS_LATENT) = w.AtmosLatent; FX(FX_ATMOS_LATENT_SUB) = w.AtmosLatentSub; FX(FX_ATMOS_SENSIBLE) = w.AtmosSensible;
+  FX(FX_LONG_UNDER_IN) = w.LongUnderIn; FX(FX_NET_LONG_ATMOS) = w.NetLongAtmos; FX(FX_NET_LONG_UNDER) = w.so.NetLongUnder;
+  FX(FX_NET_SHORT_ATMOS) = w.NetShortAtmos; FX(FX_NET_SHORT_GRND) = w.so.NetShortGrnd; FX(FX_NET_SHORT_UNDER) = w.so.NetShortUnder;
+  FX(FX_SHORT_UNDER_IN) = w.ShortUnderIn_avg;
+  FX(FX_GLAC_MASS_BALANCE) = NAN; FX(FX_GLAC_ICE_MASS_BALANCE) = 0; FX(FX_GLAC_ACCUMULATION) = NAN; FX(FX_GLAC_MELT) = NAN;
+  FX(FX_GLAC_VAPOR_FLUX) = NAN; FX(FX_GLAC_INFLOW) = NAN; FX(FX_GLAC_OUTFLOW) = NAN; FX(FX_GLAC_OUTFLOW_COEF) = NAN;
+  FX(FX_GLAC_QNET) = NAN; FX(FX_GLAC_COLD_CONTENT) = NAN; FX(FX_GLACIER_FLUX) = 0; FX(FX_DELTACC_GLAC) = 0;
+  FX(FX_GLACIER_MELT_ENERGY) = 0;
+#undef FX
+}
+
+// ------------------------------------------------------------------------------------------------ HRU kernel
+template <int NN>
+__global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= a.nhru) return;
+  const Opt& o = a.o;
+  const size_t nh = a.nhru;
+  const int c = a.hpi[(size_t)HPI_CELL * nh + g];
+  const int band = a.hpi[(size_t)HPI_BAND * nh + g];
+  const int veg_idx = a.hpi[(size_t)HPI_VEG_INDEX * nh + g];
+  const bool is_glacier = a.hpi[(size_t)HPI_IS_GLACIER * nh + g] != 0;
+  const bool is_art_bare = a.hpi[(size_t)HPI_IS_ARTIFICIAL_BARE * nh + g] != 0;
+  const double Cv = a.hpd[(size_t)HPD_CV * nh + g];
+  double root[3];
+#pragma unroll
+  for (int l = 0; l < 3; l++) root[l] = (double)(float)a.hpd[(size_t)(HPD_ROOT0 + l) * nh + g];
+  double* fx = a.flux;
+
+  int err = 0;
+  // full_energy.c:220
+  const bool active = (Cv > 0.0) || (is_glacier && o.GLACIER_DYNAMICS && Cv >= 0.0);
+  CellView cv{a.cell_params, a.ncell, c, o.Nnode, o.Nband};
+  const double area = cv.band(CPB_AREAFRACT, band);
+  const bool run = active && ((area > 0) || (is_glacier && o.GLACIER_DYNAMICS && area >= 0.0));
+  if (!run || is_glacier) {
+    // glacier HRUs are not handled by this kernel yet: flagged so that the caller sees it (never silently skipped)
+    fx[(size_t)FX_OUT_PREC * nh + g] = 0; fx[(size_t)FX_OUT_RAIN * nh + g] = 0; fx[(size_t)FX_OUT_SNOW * nh + g] = 0;
+    fx[(size_t)FX_RUNOFF * nh + g] = 0; fx[(size_t)FX_BASEFLOW * nh + g] = 0;
+    fx[(size_t)FX_EVAP0 * nh + g] = 0; fx[(size_t)FX_EVAP1 * nh + g] = 0; fx[(size_t)FX_EVAP2 * nh + g] = 0;
+    fx[(size_t)FX_CANOPYEVAP * nh + g] = 0; fx[(size_t)FX_SNOW_VAPOR_FLUX * nh + g] = 0;
+    fx[(size_t)FX_SNOW_CANOPY_VAPOR_FLUX * nh + g] = 0;
+    a.hru_err[g] = (run && is_glacier) ? VICGPU_CELLERR_SOLVER : 0;
+    return;
+  }
+  VegLib vl{a.veglib};
+  Forcing fc{a.forcing, a.snowflag, a.ncell, c, o.NR + 1};
+  const Dmy dmy = a.dmy;
+  const int month = dmy.month;
+
+  Soil3 s3;
+#pragma unroll
+  for (int l = 0; l < 3; l++) {
+    s3.depth[l] = cv.lay(CPL_DEPTH, l); s3.max_moist[l] = cv.lay(CPL_MAX_MOIST, l); s3.Wcr[l] = cv.lay(CPL_WCR, l);
+    s3.Wpwp[l] = cv.lay(CPL_WPWP, l); s3.resid_moist[l] = cv.lay(CPL_RESID_MOIST, l);
+  }
+
+  HruWork<NN> w;
+  load_state<NN>(a, g, w);
+  w.snow.vapor_flux = 0.; w.snow.canopy_vapor_flux = 0.;                  // full_energy.c:261-262
+
+  const double wind_h = vl.f(veg_idx, VL_WIND_H);
+  const double lai_cur = vl.f(veg_idx, VL_LAI + month - 1);
+  const double surf_atten = exp(-vl.f(veg_idx, VL_RAD_ATTEN) * lai_cur);   // full_energy.c:282
+
+  // prepare_full_energy.c:8-94
+  double moist0 = w.moist[0] / (s3.depth[0] * 1000.), ice0 = 0.;
+  if (o.FROZEN_SOIL && cv.s(CP_FS_ACTIVE) != 0.0) {
+    const double tm = (w.nd.T[0] + w.nd.T[1]) / 2.;
+    if (tm < 0.) {
+      ice0 = moist0 - maximum_unfrozen_water(tm, s3.max_moist[0] / (s3.depth[0] * 1000.), cv.lay(CPL_BUBBLE, 0), cv.lay(CPL_EXPT, 0));
+      if (ice0 < 0.) ice0 = 0.;
+    }
+  }
+  top_layer_thermal_properties(cv, s3, w.moist, w.ice, w.so.kappa, w.so.Cs);
+  const double bare_albedo = vl.f(veg_idx, VL_ALBEDO + month - 1);
+
+  // aerodynamic resistances for the 6 PET surfaces and the current vegetation (full_energy.c:302-354)
+  Vc aero_pet[NPET], Ra, U, disp, zref, z0;
+#pragma unroll
+  for (int k = 0; k < NCASE; k++) { disp.v[k] = NAN; zref.v[k] = NAN; z0.v[k] = NAN; U.v[k] = NAN; Ra.v[k] = NAN; }
+  bool overstory = false;
+  const double rough = cv.s(CP_ROUGH), snow_rough = cv.s(CP_SNOW_ROUGH), wind = fc.v(VIC_F_WIND, o.NR);
+#pragma unroll 1
+  for (int p = 0; p < NPET + 1; p++) {
+    const int pet_idx = (p < NPET_NON_NAT) ? o.nveg_types + p : veg_idx;
+    if (pet_idx == o.GLACIER_ID) z0.v[SNOW_FREE] = cv.s(CP_GLAC_ROUGH);      // sic: library index compared with a class id
+    else z0.v[SNOW_FREE] = vl.f(pet_idx, VL_ROUGHNESS + month - 1);
+    disp.v[SNOW_FREE] = vl.f(pet_idx, VL_DISPLACEMENT + month - 1);
+    overstory = vl.f(pet_idx, VL_OVERSTORY) != 0.0;
+    if (p >= NPET_NON_NAT && z0.v[SNOW_FREE] == 0) z0.v[SNOW_FREE] = rough;
+    const double height = calc_veg_height(disp.v[SNOW_FREE], lai_cur);
+    if (disp.v[SNOW_FREE] < wind_h) zref.v[SNOW_FREE] = wind_h;
+    else zref.v[SNOW_FREE] = disp.v[SNOW_FREE] + wind_h + z0.v[SNOW_FREE];
+    const double wind_corr = log((zref.v[SNOW_FREE] - 0.) / rough) / log((o.wind_h - 0.) / rough);
+    U.v[SNOW_FREE] = wind * wind_corr;
+    U.v[CANOPY] = NAN; U.v[SNOW_COVERED] = NAN; U.v[GLACIER_SURF] = NAN;
+#pragma unroll
+    for (int k = 0; k < NCASE; k++) Ra.v[k] = NAN;
+    if (!calc_aerodynamic(overstory, height, vl.f(pet_idx, VL_TRUNK_RATIO), snow_rough, rough, vl.f(pet_idx, VL_WIND_ATTEN), Ra, U,
+                          disp, zref, z0))
+      err |= VICGPU_CELLERR_AERO;
+    if (p < NPET) aero_pet[p] = Ra;
+  }
+  w.aero_resist_surface = Ra.v[SNOW_FREE];
+  w.aero_resist_overstory = Ra.v[CANOPY];
+#pragma unroll
+  for (int p = 0; p < NPET; p++) w.pot_evap[p] = 0;
+
+  if (!(err & VICGPU_CELLERR_AERO)) {
+    const bool ok = surface_fluxes<NN>(o, cv, vl, s3, fc, dmy, veg_idx, band, is_art_bare, overstory, bare_albedo, ice0, moist0,
+                                       surf_atten, aero_pet, Ra, U, disp, zref, z0, root, w);
+    if (!ok) err |= VICGPU_CELLERR_SOLVER;
+  }
+
+  // root zone moisture and wetness (full_energy.c:437-455)
+  w.rootmoist = 0; w.wetness = 0;
+#pragma unroll
+  for (int l = 0; l < 3; l++) {
+    if (root[l] > 0) w.rootmoist += w.moist[l];
+    w.wetness += (w.moist[l] - s3.Wpwp[l]) / (cv.lay(CPL_POROSITY, l) * s3.depth[l] * 1000 - s3.Wpwp[l]);
+  }
+  w.wetness /= 3;
+
+  bool finite = true;
+#pragma unroll
+  for (int l = 0; l < 3; l++) finite = finite && isfinite(w.moist[l]);
+  finite = finite && isfinite(w.nd.T[0]) && isfinite(w.snow.swq);
+  if (!finite) err |= VICGPU_CELLERR_NAN;
+
+  store_state<NN>(a, g, w);
+  store_flux<NN>(a, g, w);
+  a.hru_err[g] = err;
+}
+
+// ------------------------------------------------------------------------------------------------ cell kernel
+struct CArgs {
+  int ncell, nhru;
+  const int* cell_off;
+  const int* cell_list;
+  const double* hpd;
+  const double* flux;
+  const double* sd;
+  const int* hru_err;
+  double* cell_out;   // [CO_NROW][ncell]
+  double* accum;      // [CA_NROW][ncell]
+  int* cell_err;      // [ncell], OR-accumulated
+};
+
+__global__ __launch_bounds__(256) void vic_cell_reduce(const CArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.ncell) return;
+  const size_t nh = a.nhru, nc = a.ncell;
+  double op = 0, orn = 0, os = 0, ro = 0, bf = 0, ev = 0, swe = 0, sm0 = 0, sm1 = 0, sm2 = 0;
+  int err = 0;
+  for (int k = a.cell_off[c]; k < a.cell_off[c + 1]; k++) {
+    const int g = a.cell_list[k];
+    const double Cv = a.hpd[(size_t)HPD_CV * nh + g];
+    op += a.flux[(size_t)FX_OUT_PREC * nh + g] * Cv;            // full_energy.c:429-431
+    orn += a.flux[(size_t)FX_OUT_RAIN * nh + g] * Cv;
+    os += a.flux[(size_t)FX_OUT_SNOW * nh + g] * Cv;
+    ro += a.flux[(size_t)FX_RUNOFF * nh + g] * Cv;              // put_data.c:789-800 AreaFactor = Cv (mu = TreeAdjust = 1)
+    bf += a.flux[(size_t)FX_BASEFLOW * nh + g] * Cv;
+    double e = a.flux[(size_t)FX_EVAP0 * nh + g] + a.flux[(size_t)FX_EVAP1 * nh + g] + a.flux[(size_t)FX_EVAP2 * nh + g]
+               + a.flux[(size_t)FX_CANOPYEVAP * nh + g]
+               + (a.flux[(size_t)FX_SNOW_VAPOR_FLUX * nh + g] + a.flux[(size_t)FX_SNOW_CANOPY_VAPOR_FLUX * nh + g]) * 1000.;
+    ev += e * Cv;
+    swe += a.sd[(size_t)SD_SNOW_SWQ * nh + g] * 1000. * Cv;
+    sm0 += a.sd[(size_t)SD_MOIST0 * nh + g] * Cv;
+    sm1 += a.sd[(size_t)SD_MOIST1 * nh + g] * Cv;
+    sm2 += a.sd[(size_t)SD_MOIST2 * nh + g] * Cv;
+    err |= a.hru_err[g];
+  }
+  a.cell_out[(size_t)CO_OUT_PREC * nc + c] = op;
+  a.cell_out[(size_t)CO_OUT_RAIN * nc + c] = orn;
+  a.cell_out[(size_t)CO_OUT_SNOW * nc + c] = os;
+  a.accum[(size_t)CA_RUNOFF * nc + c] += ro;
+  a.accum[(size_t)CA_BASEFLOW * nc + c] += bf;
+  a.accum[(size_t)CA_EVAP * nc + c] += ev;
+  a.accum[(size_t)CA_PREC * nc + c] += op;
+  a.accum[(size_t)CA_SWE_END * nc + c] = swe;
+  a.accum[(size_t)CA_SOIL_MOIST_END0 * nc + c] = sm0;
+  a.accum[(size_t)CA_SOIL_MOIST_END1 * nc + c] = sm1;
+  a.accum[(size_t)CA_SOIL_MOIST_END2 * nc + c] = sm2;
+  a.accum[(size_t)CA_NSTEPS * nc + c] += 1.0;
+  a.cell_err[c] |= err;
+}
+
+// ------------------------------------------------------------------------------------------------ context
+struct vicgpu_ctx {
+  vicgpu_options opt;
+  Opt o;
+  int device;
+  std::string err;
+  int ncell = 0, nhru = 0, nveg_rows = 0;
+  double *d_veglib = nullptr, *d_cp = nullptr, *d_hpd = nullptr, *d_sd = nullptr, *d_flux = nullptr, *d_forcing = nullptr,
+         *d_cell_out = nullptr, *d_accum = nullptr;
+  int *d_hpi = nullptr, *d_si = nullptr, *d_cell_off = nullptr, *d_cell_list = nullptr, *d_hru_err = nullptr, *d_cell_err = nullptr;
+  unsigned char* d_snowflag = nullptr;
+  std::vector<int> dmy;            // host copy [nsteps][VIC_NDMY]
+  int chunk_steps = 0;
+  size_t forcing_cap = 0, snowflag_cap = 0;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  bool own_stream = true;
+  hipEvent_t forcing_ready = nullptr;
+  std::vector<hipEvent_t> ev;      // start/stop pairs of the last vicgpu_step call
+  int ev_used = 0;
+  int write_fluxes = 1;
+  int steps_done = 0;
+};
+
+static void free_domain(vicgpu_ctx* c) {
+  void* ps[] = {c->d_cp, c->d_hpd, c->d_sd, c->d_flux, c->d_cell_out, c->d_accum, c->d_hpi, c->d_si, c->d_cell_off, c->d_cell_list,
+                c->d_hru_err, c->d_cell_err};
+  for (void* p : ps) HIPIGN(hipFree(p));
+  c->d_cp = c->d_hpd = c->d_sd = c->d_flux = c->d_cell_out = c->d_accum = nullptr;
+  c->d_hpi = c->d_si = c->d_cell_off = c->d_cell_list = c->d_hru_err = c->d_cell_err = nullptr;
+}
+
+template <int NN>
+static hipError_t launch_hru(const KArgs& ka, hipStream_t st) {
+  const int nblk = (ka.nhru + 63) / 64;
+  hipLaunchKernelGGL(vic_hru_step<NN>, dim3(nblk), dim3(64), 0, st, ka);
+  return hipGetLastError();
+}
+
+extern "C" {
+
+int vicgpu_abi_version(void) { return VICGPU_ABI_VERSION; }
+
+const char* vicgpu_last_error(const vicgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
+  if (!opt || !out) return VICGPU_ERR_ARG;
+  *out = nullptr;
+  if (opt->abi_version != VICGPU_ABI_VERSION) return VICGPU_ERR_ARG;
+  if (opt->Nlayer != VIC_NLAYER || opt->Nnode < 3 || opt->Nnode > VIC_MAX_NODES || opt->Nband < 1 || opt->Nband > VIC_MAX_BANDS)
+    return VICGPU_ERR_UNSUPPORTED;
+  if (opt->dt <= 0 || opt->snow_step <= 0 || opt->dt % opt->snow_step != 0) return VICGPU_ERR_ARG;
+  if (opt->QUICK_FLUX && opt->Nnode != 3) return VICGPU_ERR_ARG;             // get_global_param.c:1151-1155
+  if (opt->FROZEN_SOIL && opt->QUICK_FLUX) return VICGPU_ERR_ARG;            // get_global_param.c:376-381
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VICGPU_ERR_HIP;   // no CPU fallback: fail loudly
+  if (device < 0 || device >= ndev) return VICGPU_ERR_ARG;
+  vicgpu_ctx* c = new vicgpu_ctx();
+  c->opt = *opt;
+  c->device = device;
+  Opt& o = c->o;
+  o.Nnode = opt->Nnode; o.Nband = opt->Nband; o.dt = opt->dt; o.snow_step = opt->snow_step;
+  o.NF = VICGPU_NF(opt); o.NR = VICGPU_NR(opt);
+  o.FULL_ENERGY = opt->FULL_ENERGY; o.FROZEN_SOIL = opt->FROZEN_SOIL; o.QUICK_FLUX = opt->QUICK_FLUX; o.NOFLUX = opt->NOFLUX;
+  o.EXP_TRANS = opt->EXP_TRANS; o.GRND_FLUX_TYPE = opt->GRND_FLUX_TYPE; o.TFALLBACK = opt->TFALLBACK;
+  o.AERO_RESIST_CANSNOW = opt->AERO_RESIST_CANSNOW; o.SNOW_ALBEDO = opt->SNOW_ALBEDO; o.SNOW_DENSITY = opt->SNOW_DENSITY;
+  o.TEMP_TH_TYPE = opt->TEMP_TH_TYPE; o.GLACIER_ID = opt->GLACIER_ID; o.GLACIER_DYNAMICS = opt->GLACIER_DYNAMICS;
+  o.frozen_compat = opt->frozen_compat; o.nveg_types = opt->nveg_types; o.wind_h = opt->wind_h;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return VICGPU_ERR_HIP; }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess
+      || hipEventCreateWithFlags(&c->forcing_ready, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return VICGPU_ERR_HIP;
+  }
+  *out = c;
+  return VICGPU_OK;
+}
+
+void vicgpu_destroy(vicgpu_ctx* c) {
+  if (!c) return;
+  HIPIGN(hipSetDevice(c->device));
+  if (c->stream) HIPIGN(hipStreamSynchronize(c->stream));
+  free_domain(c);
+  HIPIGN(hipFree(c->d_veglib)); HIPIGN(hipFree(c->d_forcing)); HIPIGN(hipFree(c->d_snowflag));
+  for (auto e : c->ev) HIPIGN(hipEventDestroy(e));
+  if (c->forcing_ready) HIPIGN(hipEventDestroy(c->forcing_ready));
+  if (c->own_stream && c->stream) HIPIGN(hipStreamDestroy(c->stream));
+  if (c->copy_stream) HIPIGN(hipStreamDestroy(c->copy_stream));
+  delete c;
+}
+
+int vicgpu_set_veglib(vicgpu_ctx* c, int nrow, const double* veglib) {
+  if (!c || !veglib || nrow != c->opt.nveg_types + 4) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPIGN(hipFree(c->d_veglib));
+  c->d_veglib = nullptr;
+  HIPCHK(c, hipMalloc(&c->d_veglib, sizeof(double) * nrow * VL_NFIELD));
+  HIPCHK(c, hipMemcpy(c->d_veglib, veglib, sizeof(double) * nrow * VL_NFIELD, hipMemcpyHostToDevice));
+  c->nveg_rows = nrow;
+  return VICGPU_OK;
+}
+
+int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_params, const int* hpi, const double* hpd,
+                      const int* cell_hru_offset, const int* cell_hru_list) {
+  if (!c || ncell <= 0 || nhru <= 0 || !cell_params || !hpi || !hpd || !cell_hru_offset || !cell_hru_list) return VICGPU_ERR_ARG;
+  // host-side shape checks: every index the kernels dereference is validated here, once
+  if (cell_hru_offset[0] != 0 || cell_hru_offset[ncell] != nhru) return VICGPU_ERR_ARG;
+  for (int i = 0; i < ncell; i++) if (cell_hru_offset[i + 1] < cell_hru_offset[i]) return VICGPU_ERR_ARG;
+  {
+    std::vector<char> seen(nhru, 0);
+    for (int i = 0; i < ncell; i++)
+      for (int k = cell_hru_offset[i]; k < cell_hru_offset[i + 1]; k++) {
+        int g = cell_hru_list[k];
+        if (g < 0 || g >= nhru || seen[g] || hpi[(size_t)HPI_CELL * nhru + g] != i) return VICGPU_ERR_ARG;
+        seen[g] = 1;
+      }
+    for (int g = 0; g < nhru; g++) {
+      if (!seen[g]) return VICGPU_ERR_ARG;
+      int b = hpi[(size_t)HPI_BAND * nhru + g], v = hpi[(size_t)HPI_VEG_INDEX * nhru + g];
+      if (b < 0 || b >= c->opt.Nband || v < 0 || v >= c->opt.nveg_types + 4) return VICGPU_ERR_ARG;
+    }
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  free_domain(c);
+  c->ncell = ncell; c->nhru = nhru;
+  const size_t cp_n = (size_t)VICGPU_CP_NROW(c->opt.Nnode, c->opt.Nband) * ncell;
+  const size_t sd_n = (size_t)VICGPU_SD_NROW(c->opt.Nnode) * nhru, si_n = (size_t)VICGPU_SI_NROW(c->opt.Nnode) * nhru;
+  HIPCHK(c, hipMalloc(&c->d_cp, sizeof(double) * cp_n));
+  HIPCHK(c, hipMalloc(&c->d_hpi, sizeof(int) * HPI_NROW * nhru));
+  HIPCHK(c, hipMalloc(&c->d_hpd, sizeof(double) * HPD_NROW * nhru));
+  HIPCHK(c, hipMalloc(&c->d_cell_off, sizeof(int) * (ncell + 1)));
+  HIPCHK(c, hipMalloc(&c->d_cell_list, sizeof(int) * nhru));
+  HIPCHK(c, hipMalloc(&c->d_sd, sizeof(double) * sd_n));
+  HIPCHK(c, hipMalloc(&c->d_si, sizeof(int) * si_n));
+  HIPCHK(c, hipMalloc(&c->d_flux, sizeof(double) * FX_NROW * nhru));
+  HIPCHK(c, hipMalloc(&c->d_cell_out, sizeof(double) * CO_NROW * ncell));
+  HIPCHK(c, hipMalloc(&c->d_accum, sizeof(double) * CA_NROW * ncell));
+  HIPCHK(c, hipMalloc(&c->d_hru_err, sizeof(int) * nhru));
+  HIPCHK(c, hipMalloc(&c->d_cell_err, sizeof(int) * ncell));
+  HIPCHK(c, hipMemcpy(c->d_cp, cell_params, sizeof(double) * cp_n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_hpi, hpi, sizeof(int) * HPI_NROW * nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_hpd, hpd, sizeof(double) * HPD_NROW * nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_cell_off, cell_hru_offset, sizeof(int) * (ncell + 1), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_cell_list, cell_hru_list, sizeof(int) * nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(c->d_sd, 0, sizeof(double) * sd_n));
+  HIPCHK(c, hipMemset(c->d_si, 0, sizeof(int) * si_n));
+  HIPCHK(c, hipMemset(c->d_flux, 0, sizeof(double) * FX_NROW * nhru));
+  HIPCHK(c, hipMemset(c->d_cell_out, 0, sizeof(double) * CO_NROW * ncell));
+  HIPCHK(c, hipMemset(c->d_accum, 0, sizeof(double) * CA_NROW * ncell));
+  HIPCHK(c, hipMemset(c->d_hru_err, 0, sizeof(int) * nhru));
+  HIPCHK(c, hipMemset(c->d_cell_err, 0, sizeof(int) * ncell));
+  return VICGPU_OK;
+}
+
+int vicgpu_set_state(vicgpu_ctx* c, const double* sd, const int* si) {
+  if (!c || !c->d_sd || !sd || !si) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->d_sd, sd, sizeof(double) * VICGPU_SD_NROW(c->opt.Nnode) * c->nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_si, si, sizeof(int) * VICGPU_SI_NROW(c->opt.Nnode) * c->nhru, hipMemcpyHostToDevice));
+  return VICGPU_OK;
+}
+
+int vicgpu_get_state(vicgpu_ctx* c, double* sd, int* si) {
+  if (!c || !c->d_sd || !sd || !si) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(sd, c->d_sd, sizeof(double) * VICGPU_SD_NROW(c->opt.Nnode) * c->nhru, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(si, c->d_si, sizeof(int) * VICGPU_SI_NROW(c->opt.Nnode) * c->nhru, hipMemcpyDeviceToHost));
+  return VICGPU_OK;
+}
+
+int vicgpu_push_forcing(vicgpu_ctx* c, int nsteps, const double* forcing, const unsigned char* snowflag, const int* dmy) {
+  if (!c || !c->d_cp || nsteps <= 0 || !forcing || !snowflag || !dmy) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nsub = c->o.NR + 1;
+  const size_t fbytes = sizeof(double) * (size_t)nsteps * VIC_NFORCE * nsub * c->ncell;
+  const size_t sbytes = (size_t)nsteps * nsub * c->ncell;
+  for (int s = 0; s < nsteps; s++) {
+    int m = dmy[(size_t)s * VIC_NDMY + VIC_DMY_MONTH];
+    if (m < 1 || m > 12) return VICGPU_ERR_ARG;          // month indexes the veg library tables
+  }
+  // the previous chunk may still be read by queued kernels
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (fbytes > c->forcing_cap) {
+    HIPIGN(hipFree(c->d_forcing)); c->d_forcing = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_forcing, fbytes));
+    c->forcing_cap = fbytes;
+  }
+  if (sbytes > c->snowflag_cap) {
+    HIPIGN(hipFree(c->d_snowflag)); c->d_snowflag = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_snowflag, sbytes));
+    c->snowflag_cap = sbytes;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_forcing, forcing, fbytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_snowflag, snowflag, sbytes, hipMemcpyHostToDevice, c->copy_stream));
+  HIPCHK(c, hipEventRecord(c->forcing_ready, c->copy_stream));
+  c->dmy.assign(dmy, dmy + (size_t)nsteps * VIC_NDMY);
+  c->chunk_steps = nsteps;
+  return VICGPU_OK;
+}
+
+int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
+  if (!c || !c->d_cp || !c->d_veglib || !c->d_forcing) return VICGPU_ERR_STATE;
+  if (step0 < 0 || nsteps <= 0 || step0 + nsteps > c->chunk_steps) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->forcing_ready, 0));
+  while ((int)c->ev.size() < 2 * nsteps) {
+    hipEvent_t e;
+    HIPCHK(c, hipEventCreate(&e));
+    c->ev.push_back(e);
+  }
+  c->ev_used = 0;
+  const size_t nsub = c->o.NR + 1;
+  KArgs ka;
+  ka.o = c->o; ka.ncell = c->ncell; ka.nhru = c->nhru; ka.nveg_rows = c->nveg_rows; ka.write_fluxes = c->write_fluxes;
+  ka.veglib = c->d_veglib; ka.cell_params = c->d_cp; ka.hpi = c->d_hpi; ka.hpd = c->d_hpd;
+  ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
+  CArgs ca;
+  ca.ncell = c->ncell; ca.nhru = c->nhru; ca.cell_off = c->d_cell_off; ca.cell_list = c->d_cell_list; ca.hpd = c->d_hpd;
+  ca.flux = c->d_flux; ca.sd = c->d_sd; ca.hru_err = c->d_hru_err; ca.cell_out = c->d_cell_out; ca.accum = c->d_accum;
+  ca.cell_err = c->d_cell_err;
+  for (int s = step0; s < step0 + nsteps; s++) {
+    ka.forcing = c->d_forcing + (size_t)s * VIC_NFORCE * nsub * c->ncell;
+    ka.snowflag = c->d_snowflag + (size_t)s * nsub * c->ncell;
+    const int* d = &c->dmy[(size_t)s * VIC_NDMY];
+    ka.dmy.month = d[VIC_DMY_MONTH]; ka.dmy.day_in_year = d[VIC_DMY_DAY_IN_YEAR]; ka.dmy.hour = d[VIC_DMY_HOUR];
+    ka.dmy.day = d[VIC_DMY_DAY]; ka.dmy.year = d[VIC_DMY_YEAR];
+    HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0)], c->stream));
+    hipError_t e;
+    if (c->o.Nnode == 3) e = launch_hru<3>(ka, c->stream);
+    else if (c->o.Nnode == 10) e = launch_hru<10>(ka, c->stream);
+    else e = launch_hru<VIC_MAX_NODES>(ka, c->stream);
+    HIPCHK(c, e);
+    HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0) + 1], c->stream));
+    hipLaunchKernelGGL(vic_cell_reduce, dim3((c->ncell + 255) / 256), dim3(256), 0, c->stream, ca);
+    HIPCHK(c, hipGetLastError());
+    c->steps_done++;
+  }
+  c->ev_used = nsteps;
+  return VICGPU_OK;
+}
+
+int vicgpu_synchronize(vicgpu_ctx* c) {
+  if (!c) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VICGPU_OK;
+}
+
+int vicgpu_last_kernel_ms(vicgpu_ctx* c, double* ms_per_launch, int* nlaunch) {
+  if (!c || !ms_per_launch) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double tot = 0;
+  for (int i = 0; i < c->ev_used; i++) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]));
+    tot += ms;
+  }
+  *ms_per_launch = c->ev_used ? tot / c->ev_used : 0.0;
+  if (nlaunch) *nlaunch = c->ev_used;
+  return VICGPU_OK;
+}
+
+static int d2h(vicgpu_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || !dst || !src) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return VICGPU_OK;
+}
+
+int vicgpu_get_fluxes(vicgpu_ctx* c, double* flux) { return c ? d2h(c, flux, c->d_flux, sizeof(double) * FX_NROW * c->nhru) : VICGPU_ERR_ARG; }
+int vicgpu_get_cell_outputs(vicgpu_ctx* c, double* o) { return c ? d2h(c, o, c->d_cell_out, sizeof(double) * CO_NROW * c->ncell) : VICGPU_ERR_ARG; }
+int vicgpu_get_accum(vicgpu_ctx* c, double* a) { return c ? d2h(c, a, c->d_accum, sizeof(double) * CA_NROW * c->ncell) : VICGPU_ERR_ARG; }
+int vicgpu_get_cell_errors(vicgpu_ctx* c, int* f) { return c ? d2h(c, f, c->d_cell_err, sizeof(int) * c->ncell) : VICGPU_ERR_ARG; }
+
+int vicgpu_reset_accum(vicgpu_ctx* c) {
+  if (!c || !c->d_accum) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemsetAsync(c->d_accum, 0, sizeof(double) * CA_NROW * c->ncell, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_cell_err, 0, sizeof(int) * c->ncell, c->stream));
+  return VICGPU_OK;
+}
+
+int vicgpu_set_stream(vicgpu_ctx* c, void* hip_stream) {
+  if (!c) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (hip_stream) {
+    if (c->own_stream) HIPIGN(hipStreamDestroy(c->stream));
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+  } else if (!c->own_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return VICGPU_OK;
+}
+
+int vicgpu_set_write_fluxes(vicgpu_ctx* c, int on) {
+  if (!c) return VICGPU_ERR_ARG;
+  c->write_fluxes = on ? 1 : 0;
+  return VICGPU_OK;
+}
+
+void* vicgpu_device_ptr(vicgpu_ctx* c, int which) {
+  if (!c) return nullptr;
+  switch (which) {
+    case VICGPU_PTR_STATE_D: return c->d_sd;
+    case VICGPU_PTR_STATE_I: return c->d_si;
+    case VICGPU_PTR_FLUX: return c->d_flux;
+    case VICGPU_PTR_FORCING: return c->d_forcing;
+    case VICGPU_PTR_ACCUM: return c->d_accum;
+    case VICGPU_PTR_CELL_OUT: return c->d_cell_out;
+    default: return nullptr;
+  }
+}
+
+}  // extern "C"

@@ -104,42 +104,48 @@ def zwt_tables(depth, expt, bubble, max_moist, resid_moist):
             w = np.clip(w, 0, 1)
             mst[nl, i] = w * (tmm - trm) + trm
             zp = zp + tmp_depth * 100 / (NZ - 1)
-        # whole column filled from the bottom up (:1235-1284); scalar loop per cell (ingest-time only)
+        # whole column filled from the bottom up (:1235-1284), vectorised over cells with masks for the layer walks
         tot = depth.sum(axis=0)
-        for c in range(nc):
-            zp = 0.0
-            d = depth[:, c]
-            for i in range(NZ):
-                zwt[nl + 1, i, c] = -zp
-                if zp == 0:
-                    mst[nl + 1, i, c] = max_moist[:, c].sum()
-                else:
-                    tm = 0.0
-                    l = nl - 1
-                    td2 = tot[c] - d[l]
-                    while l > 0 and zp <= td2 * 100:
-                        tm += max_moist[l, c]
-                        l -= 1
-                        td2 -= d[l]
-                    w = (td2 * 100 + d[l] * 100 - zp) / (d[l] * 100)
-                    b = 0.5 * (expt[l, c] - 3)
-                    bub = bubble[l, c]
-                    resid = resid_moist[l, c] * d[l] * 1000
-                    w += -(b / (b - 1)) * bub * (1 - np.power((zp + bub - td2 * 100) / bub, (b - 1) / b)) / (d[l] * 100)
-                    tm += w * (max_moist[l, c] - resid) + resid
-                    b_save, bub_save, td2_save = b, bub, td2
-                    while l > 0:
-                        l -= 1
-                        td2 -= d[l]
-                        b = 0.5 * (expt[l, c] - 3)
-                        bub = bubble[l, c]
-                        resid = resid_moist[l, c] * d[l] * 1000
-                        zpe = td2_save * 100 - bub + bub * np.power((zp + bub_save - td2_save * 100) / bub_save, b / b_save)
-                        w = -(b / (b - 1)) * bub * (1 - np.power((zpe + bub - td2 * 100) / bub, (b - 1) / b)) / (d[l] * 100)
-                        tm += w * (max_moist[l, c] - resid) + resid
-                        b_save, bub_save, td2_save = b, bub, td2
-                    mst[nl + 1, i, c] = tm
-                zp += tot[c] * 100 / (NZ - 1)
+        cidx = np.arange(nc)
+        zp = np.zeros(nc)
+        for i in range(NZ):
+            zwt[nl + 1, i] = -zp
+            if i == 0:
+                mst[nl + 1, i] = max_moist.sum(axis=0)
+            else:
+                tm = np.zeros(nc)
+                l = np.full(nc, nl - 1)
+                td2 = tot - depth[nl - 1]
+                for _ in range(nl - 1):
+                    go = (l > 0) & (zp <= td2 * 100)
+                    tm = np.where(go, tm + max_moist[l, cidx], tm)
+                    l = np.where(go, l - 1, l)
+                    td2 = np.where(go, td2 - depth[l, cidx], td2)
+                dl = depth[l, cidx]
+                w = (td2 * 100 + dl * 100 - zp) / (dl * 100)
+                b = 0.5 * (expt[l, cidx] - 3)
+                bub = bubble[l, cidx]
+                resid = resid_moist[l, cidx] * dl * 1000
+                w = w + (-(b / (b - 1)) * bub * (1 - np.power((zp + bub - td2 * 100) / bub, (b - 1) / b)) / (dl * 100))
+                tm = tm + (w * (max_moist[l, cidx] - resid) + resid)
+                b_save, bub_save, td2_save = b, bub, td2
+                for _ in range(nl - 1):
+                    go = l > 0
+                    l2 = np.where(go, l - 1, l)
+                    dl = depth[l2, cidx]
+                    td2n = td2 - dl
+                    b = 0.5 * (expt[l2, cidx] - 3)
+                    bub = bubble[l2, cidx]
+                    resid = resid_moist[l2, cidx] * dl * 1000
+                    zpe = td2_save * 100 - bub + bub * np.power((zp + bub_save - td2_save * 100) / bub_save, b / b_save)
+                    w = -(b / (b - 1)) * bub * (1 - np.power((zpe + bub - td2n * 100) / bub, (b - 1) / b)) / (dl * 100)
+                    tm = np.where(go, tm + (w * (max_moist[l2, cidx] - resid) + resid), tm)
+                    b_save = np.where(go, b, b_save); bub_save = np.where(go, bub, bub_save)
+                    td2_save = np.where(go, td2n, td2_save)
+                    td2 = np.where(go, td2n, td2)
+                    l = l2
+                mst[nl + 1, i] = tm
+            zp = zp + tot * 100 / (NZ - 1)
     return zwt, mst
 
 
