@@ -870,3 +870,13 @@ double orc_solve_snow(const orc_model *m, int overstory, double BareAlbedo, doub
   energy->melt_energy *= -1.;
   return melt;
 }
+
+/* exported wrappers for orc_glacier.c (solve_snow_glac uses the same snow_utility.c functions) */
+double orc_snow_albedo_x(const orc_model *m, double new_snow, double swq, double depth, double albedo, double cold_content,
+                         double dt, int last_snow, int MELTING, const orc_soil *sc) {
+  return orc_snow_albedo(m, new_snow, swq, depth, albedo, cold_content, dt, last_snow, MELTING, sc);
+}
+double orc_snow_density_x(const orc_model *m, const orc_snow *snow, double new_snow, double sswq, double Tair, double dt) {
+  return orc_snow_density(m, snow, new_snow, sswq, Tair, dt);
+}
+double orc_new_snow_density_x(const orc_model *m, double air_temp) { return orc_new_snow_density(m, air_temp); }

@@ -31,7 +31,7 @@ def run(opt_kw, ncell=6, ntile=3, nsteps=240, start_doy=1, variant="plain", cold
             dd = np.where(np.isnan(dd), np.inf, dd)
             dd = np.where((a == b), 0, dd)
             return dd
-        ds = rel(sr, so); df = rel(fr[:C["FX_OUT_PREC"]], fo[:C["FX_OUT_PREC"]]); dc = rel(cr, co)
+        ds = rel(sr, so); rows = [r for r in range(C["FX_NROW"]) if r not in (C["FX_OUT_PREC"], C["FX_OUT_RAIN"], C["FX_OUT_SNOW"])]; df = rel(fr[rows], fo[rows]); dc = rel(cr, co)
         m = max(ds.max(), df.max(), dc.max(), float((ir != io).any()))
         worst = max(worst, m)
         if m > 1e-9 and verbose:
@@ -39,7 +39,7 @@ def run(opt_kw, ncell=6, ntile=3, nsteps=240, start_doy=1, variant="plain", cold
             r, c = np.unravel_index(np.argmax(ds), ds.shape)
             print("   state row", r, sdn.get(r, "node+%d" % (r - C["SD_NSCALAR"])), "hru", c, sr[r, c], so[r, c])
             r, c = np.unravel_index(np.argmax(df), df.shape)
-            print("   flux row", r, fxn.get(r), "hru", c, fr[r, c], fo[r, c])
+            print("   flux row", rows[r], fxn.get(rows[r]), "hru", c, fr[rows[r], c], fo[rows[r], c])
             if (ir != io).any():
                 r, c = np.argwhere(ir != io)[0]
                 print("   int row", r, "hru", c, ir[r, c], io[r, c])
