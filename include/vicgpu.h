@@ -198,6 +198,7 @@ enum {
   SD_ADVECTED_SENSIBLE, SD_ADVECTION, SD_DELTACC, SD_REFREEZE_ENERGY, SD_MELT_ENERGY, SD_ERROR,
   SD_LATENT, SD_LATENT_SUB, SD_SENSIBLE,
   SD_LONGOVERIN, SD_NETLONGOVER, SD_NETSHORTOVER, SD_SHORTOVERIN,
+  SD_NETLONGUNDER,   /* glacier HRUs feed last step's NetLongUnder into compute_pot_evap (surface_fluxes_glac.c:343,380) */
   SD_NSCALAR
 };
 /* per-node fields (x Nnode): T is prognostic; the other four are what

@@ -537,6 +537,7 @@ int vicorc_get_state(void *hv, double *sd, int *si) {
     SDP(SD_MELT_ENERGY) = e->melt_energy; SDP(SD_ERROR) = e->error; SDP(SD_LATENT) = e->latent;
     SDP(SD_LATENT_SUB) = e->latent_sub; SDP(SD_SENSIBLE) = e->sensible; SDP(SD_LONGOVERIN) = e->LongOverIn;
     SDP(SD_NETLONGOVER) = e->NetLongOver; SDP(SD_NETSHORTOVER) = e->NetShortOver; SDP(SD_SHORTOVERIN) = e->ShortOverIn;
+    SDP(SD_NETLONGUNDER) = e->NetLongUnder;
     for (n = 0; n < Nn; n++) {
       SDP(VICGPU_SD_NODE(SDN_T, n, Nn)) = e->T[n]; SDP(VICGPU_SD_NODE(SDN_MOIST, n, Nn)) = e->moist[n];
       SDP(VICGPU_SD_NODE(SDN_ICE, n, Nn)) = e->ice[n]; SDP(VICGPU_SD_NODE(SDN_KAPPA, n, Nn)) = e->kappa_node[n];
@@ -580,6 +581,7 @@ int vicorc_set_state(void *hv, const double *sd, const int *si) {
     e->melt_energy = SDP(SD_MELT_ENERGY); e->error = SDP(SD_ERROR); e->latent = SDP(SD_LATENT);
     e->latent_sub = SDP(SD_LATENT_SUB); e->sensible = SDP(SD_SENSIBLE); e->LongOverIn = SDP(SD_LONGOVERIN);
     e->NetLongOver = SDP(SD_NETLONGOVER); e->NetShortOver = SDP(SD_NETSHORTOVER); e->ShortOverIn = SDP(SD_SHORTOVERIN);
+    e->NetLongUnder = SDP(SD_NETLONGUNDER);
     for (n = 0; n < Nn; n++) {
       e->T[n] = SDP(VICGPU_SD_NODE(SDN_T, n, Nn)); e->moist[n] = SDP(VICGPU_SD_NODE(SDN_MOIST, n, Nn));
       e->ice[n] = SDP(VICGPU_SD_NODE(SDN_ICE, n, Nn)); e->kappa_node[n] = SDP(VICGPU_SD_NODE(SDN_KAPPA, n, Nn));

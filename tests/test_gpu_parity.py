@@ -16,15 +16,25 @@ from tests.util import rel_diff, worst, FLUX_ROWS_COMMON
 
 pytestmark = pytest.mark.gpu
 
+GLACIER_ROWS = [C[k] for k in ("FX_GLAC_MASS_BALANCE", "FX_GLAC_ICE_MASS_BALANCE", "FX_GLAC_ACCUMULATION", "FX_GLAC_MELT",
+                               "FX_GLAC_VAPOR_FLUX", "FX_GLAC_INFLOW", "FX_GLAC_OUTFLOW", "FX_GLAC_OUTFLOW_COEF")]
+
 TF_TOL = 1e-6      # teacher-forced, relative (floor 1e-6 absolute units)
 FREE_TOL = 1e-5    # free-running headline outputs
 
 
 def _setup(kw, ncell, ntile, nsteps, start_doy, cold=0.0):
+    kw = dict(kw)
+    glacier = kw.pop("glacier", False)
     opt = abi.default_options(**kw)
-    d = domain.make_domain(ncell, opt, ntile=ntile)
+    d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
     f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=start_doy, cold=cold)
     sd0, si0 = init_state.initial_state(d, f[0])
+    if glacier:
+        # the driver opens the glacier mass-balance accumulation window by making cum_mass_balance valid
+        # (accumulateGlacierMassBalance.c:13-67)
+        isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+        sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
     return d, f, sf, dmy, sd0, si0
 
 
@@ -37,6 +47,10 @@ CASES = {
     "frozen_fixed": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=0), 32, 3, 1),
     "frozen_compat": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=1), 32, 3, 1),
     "frozen_fixed_n8": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=8, frozen_compat=0), 32, 2, 300),
+    "glacier_winter": (dict(FULL_ENERGY=1, Nband=3, glacier=True), 32, 2, 1),
+    "glacier_summer": (dict(FULL_ENERGY=1, Nband=3, glacier=True), 32, 2, 190),
+    "glacier_frozen": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=2, frozen_compat=0, glacier=True), 32, 2, 120),
+    "glacier_daily": (dict(FULL_ENERGY=0, dt=24, snow_step=3, Nband=2, glacier=True), 32, 2, 100),
 }
 
 
@@ -66,7 +80,8 @@ def test_teacher_forced(name, oracle_lib):
         assert np.nanmax(np.abs(so[C["SD_ERROR"]] - sg[C["SD_ERROR"]])) < 1e-3
         so[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
         w1, m1 = worst(so, sg, "SD_", floor=1e-6)
-        w2, m2 = worst(fo[FLUX_ROWS_COMMON], fg[FLUX_ROWS_COMMON], "FX_", floor=1e-6)
+        rows = FLUX_ROWS_COMMON + (GLACIER_ROWS if kw.get("glacier") else [])
+        w2, m2 = worst(fo[rows], fg[rows], "FX_", floor=1e-6)
         w3, m3 = worst(co, cg, "CO_", floor=1e-6)
         assert w1 < TF_TOL, "step %d state %s" % (s, m1)
         assert w2 < TF_TOL, "step %d flux %s" % (s, m2)
@@ -77,7 +92,7 @@ def test_teacher_forced(name, oracle_lib):
     print(name, "teacher-forced worst rel diff %.3e" % worst_all)
 
 
-@pytest.mark.parametrize("name", ["quickflux_melt", "bands", "waterbalance_daily", "frozen_fixed"])
+@pytest.mark.parametrize("name", ["quickflux_melt", "bands", "waterbalance_daily", "frozen_fixed", "glacier_summer"])
 def test_free_running(name, oracle_lib):
     """Both run freely from the same initial state; per-cell accumulated headline outputs within 1e-5 relative."""
     from vic_amd.api import Model
@@ -111,6 +126,11 @@ def test_free_running(name, oracle_lib):
               "evap": (ev, acc[C["CA_EVAP"]], 1e-3), "swe": (swe, acc[C["CA_SWE_END"]], 1e-3),
               "soil_moist0": (sm[0], acc[C["CA_SOIL_MOIST_END0"]], 1e-3), "soil_moist1": (sm[1], acc[C["CA_SOIL_MOIST_END1"]], 1e-3),
               "soil_moist2": (sm[2], acc[C["CA_SOIL_MOIST_END2"]], 1e-3)}
+    if kw.get("glacier"):
+        isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+        sg, _ = gpu.get_state()
+        checks["glacier_cum_mass_balance"] = (so[C["SD_GLAC_CUM_MASS_BALANCE"], isg], sg[C["SD_GLAC_CUM_MASS_BALANCE"], isg], 1e-4)
+        checks["glacier_water_storage"] = (so[C["SD_GLAC_WATER_STORAGE"], isg], sg[C["SD_GLAC_WATER_STORAGE"], isg], 1e-4)
     for k, (a, b, fl) in checks.items():
         dmax = rel_diff(a, b, floor=fl).max()
         print(name, k, "max rel diff %.3e" % dmax, "range", float(a.min()), float(a.max()))

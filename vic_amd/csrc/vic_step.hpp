@@ -162,6 +162,9 @@ struct HruWork {
   double AtmosLatent, AtmosLatentSub, AtmosSensible, LongUnderIn, NetLongAtmos, NetShortAtmos, ShortUnderIn_avg, AlbedoOver_avg,
          AlbedoUnder_avg, LongOverIn_avg, NetLongOver_avg, NetShortOver_avg, ShortOverIn_avg;
   double out_prec, out_rain, out_snow;
+  // glacier HRUs only
+  Glac gl;
+  double deltaCC_glac, glacier_flux, glacier_melt_energy;
 };
 
 // surface_fluxes (surface_fluxes.c:17-956) with CLOSE_ENERGY FALSE (both closure loops execute once), Ndist 1.

@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 #include "vicgpu.h"
-#include "vic_step.hpp"
+#include "vic_glacier.hpp"
 
 using namespace vic;
 
@@ -80,7 +80,12 @@ VIC_DEV void load_state(const KArgs& a, int g, HruWork<NN>& w) {
   se.snow_flux = so.snow_flux;
   se.LongOverIn = SD(SD_LONGOVERIN); se.NetLongOver = SD(SD_NETLONGOVER); se.NetShortOver = SD(SD_NETSHORTOVER);
   se.ShortOverIn = SD(SD_SHORTOVERIN);
-  so.NetShortGrnd = 0; so.NetLongUnder = 0; so.NetShortUnder = 0;
+  so.NetShortGrnd = 0; so.NetLongUnder = SD(SD_NETLONGUNDER); so.NetShortUnder = 0;
+  w.gl.surf_temp = SD(SD_GLAC_SURF_TEMP); w.gl.water_storage = SD(SD_GLAC_WATER_STORAGE);
+  w.gl.cum_mass_balance = SD(SD_GLAC_CUM_MASS_BALANCE);
+  w.gl.cold_content = NAN; w.gl.Qnet = NAN; w.gl.mass_balance = NAN; w.gl.ice_mass_balance = 0; w.gl.accumulation = NAN;
+  w.gl.melt = NAN; w.gl.vapor_flux = NAN; w.gl.outflow = NAN; w.gl.outflow_coef = NAN; w.gl.inflow = NAN;
+  w.deltaCC_glac = 0; w.glacier_flux = 0; w.glacier_melt_energy = 0;
   so.kappa[0] = so.kappa[1] = so.Cs[0] = so.Cs[1] = 0;
 #pragma unroll
   for (int f = 0; f < 3; f++) { so.fdepth[f] = 0; so.tdepth[f] = 0; }
@@ -100,6 +105,7 @@ VIC_DEV void load_state(const KArgs& a, int g, HruWork<NN>& w) {
   so.Tsurf_fbcount = SI(SI_TSURF_FBCOUNT); so.Tsurf_fbflag = SI(SI_TSURF_FBFLAG);
   se.Tfoliage_fbcount = SI(SI_TFOLIAGE_FBCOUNT); se.Tfoliage_fbflag = SI(SI_TFOLIAGE_FBFLAG);
   so.frozen = SI(SI_FROZEN); so.Nfrost = SI(SI_NFROST); so.Nthaw = SI(SI_NTHAW);
+  w.gl.surf_temp_fbcount = SI(SI_GLAC_SURF_TEMP_FBCOUNT); w.gl.surf_temp_fbflag = SI(SI_GLAC_SURF_TEMP_FBFLAG);
 #undef SD
 #undef SI
 }
@@ -130,7 +136,9 @@ VIC_DEV void store_state(const KArgs& a, int g, const HruWork<NN>& w) {
   SD(SD_ADVECTION) = so.advection; SD(SD_DELTACC) = so.deltaCC; SD(SD_REFREEZE_ENERGY) = so.refreeze_energy;
   SD(SD_MELT_ENERGY) = so.melt_energy; SD(SD_ERROR) = so.error; SD(SD_LATENT) = so.latent; SD(SD_LATENT_SUB) = so.latent_sub;
   SD(SD_SENSIBLE) = so.sensible; SD(SD_LONGOVERIN) = w.LongOverIn_avg; SD(SD_NETLONGOVER) = w.NetLongOver_avg;
-  SD(SD_NETSHORTOVER) = w.NetShortOver_avg; SD(SD_SHORTOVERIN) = w.ShortOverIn_avg;
+  SD(SD_NETSHORTOVER) = w.NetShortOver_avg; SD(SD_SHORTOVERIN) = w.ShortOverIn_avg; SD(SD_NETLONGUNDER) = so.NetLongUnder;
+  SD(SD_GLAC_SURF_TEMP) = w.gl.surf_temp; SD(SD_GLAC_WATER_STORAGE) = w.gl.water_storage;
+  SD(SD_GLAC_CUM_MASS_BALANCE) = w.gl.cum_mass_balance;
 #pragma unroll
   for (int n = 0; n < NN; n++) {
     if (n < Nn) {
@@ -145,6 +153,7 @@ VIC_DEV void store_state(const KArgs& a, int g, const HruWork<NN>& w) {
   SI(SI_TSURF_FBCOUNT) = so.Tsurf_fbcount; SI(SI_TSURF_FBFLAG) = so.Tsurf_fbflag;
   SI(SI_TFOLIAGE_FBCOUNT) = se.Tfoliage_fbcount; SI(SI_TFOLIAGE_FBFLAG) = se.Tfoliage_fbflag;
   SI(SI_FROZEN) = so.frozen; SI(SI_NFROST) = so.Nfrost; SI(SI_NTHAW) = so.Nthaw;
+  SI(SI_GLAC_SURF_TEMP_FBCOUNT) = w.gl.surf_temp_fbcount; SI(SI_GLAC_SURF_TEMP_FBFLAG) = w.gl.surf_temp_fbflag;
 #undef SD
 #undef SI
 }
@@ -159,7 +168,7 @@ VIC_DEV void store_flux(const KArgs& a, int g, const HruWork<NN>& w) {
   FX(FX_RUNOFF) = w.runoff; FX(FX_BASEFLOW) = w.baseflow;
   FX(FX_EVAP0) = w.evap[0]; FX(FX_EVAP1) = w.evap[1]; FX(FX_EVAP2) = w.evap[2];
   FX(FX_CANOPYEVAP) = w.vv.canopyevap; FX(FX_SNOW_VAPOR_FLUX) = w.snow.vapor_flux;
-  FX(FX_SNOW_CANOPY_VAPOR_FLUX) = w.snow.canopy_vapor_flux;
+  FX(FX_SNOW_CANOPY_VAPOR_FLUX) = w.snow.canopy_vapor_flux; FX(FX_GLAC_MASS_BALANCE) = w.gl.mass_balance;
   if (!a.write_fluxes) return;
   FX(FX_ASAT) = w.asat; FX(FX_INFLOW) = w.inflow; FX(FX_THROUGHFALL) = w.vv.throughfall;
   FX(FX_SNOW_BLOWING_FLUX) = w.snow.blowing_flux; FX(FX_SNOW_SURFACE_FLUX) = w.snow.surface_flux; FX(FX_SNOW_MELT) = w.snow.melt;
@@ -173,15 +182,16 @@ VIC_DEV void store_flux(const KArgs& a, int g, const HruWork<NN>& w) {
   FX(FX_LONG_UNDER_IN) = w.LongUnderIn; FX(FX_NET_LONG_ATMOS) = w.NetLongAtmos; FX(FX_NET_LONG_UNDER) = w.so.NetLongUnder;
   FX(FX_NET_SHORT_ATMOS) = w.NetShortAtmos; FX(FX_NET_SHORT_GRND) = w.so.NetShortGrnd; FX(FX_NET_SHORT_UNDER) = w.so.NetShortUnder;
   FX(FX_SHORT_UNDER_IN) = w.ShortUnderIn_avg;
-  FX(FX_GLAC_MASS_BALANCE) = NAN; FX(FX_GLAC_ICE_MASS_BALANCE) = 0; FX(FX_GLAC_ACCUMULATION) = NAN; FX(FX_GLAC_MELT) = NAN;
-  FX(FX_GLAC_VAPOR_FLUX) = NAN; FX(FX_GLAC_INFLOW) = NAN; FX(FX_GLAC_OUTFLOW) = NAN; FX(FX_GLAC_OUTFLOW_COEF) = NAN;
-  FX(FX_GLAC_QNET) = NAN; FX(FX_GLAC_COLD_CONTENT) = NAN; FX(FX_GLACIER_FLUX) = 0; FX(FX_DELTACC_GLAC) = 0;
-  FX(FX_GLACIER_MELT_ENERGY) = 0;
+  FX(FX_GLAC_ICE_MASS_BALANCE) = w.gl.ice_mass_balance; FX(FX_GLAC_ACCUMULATION) = w.gl.accumulation;
+  FX(FX_GLAC_MELT) = w.gl.melt; FX(FX_GLAC_VAPOR_FLUX) = w.gl.vapor_flux; FX(FX_GLAC_INFLOW) = w.gl.inflow;
+  FX(FX_GLAC_OUTFLOW) = w.gl.outflow; FX(FX_GLAC_OUTFLOW_COEF) = w.gl.outflow_coef; FX(FX_GLAC_QNET) = w.gl.Qnet;
+  FX(FX_GLAC_COLD_CONTENT) = w.gl.cold_content; FX(FX_GLACIER_FLUX) = w.glacier_flux; FX(FX_DELTACC_GLAC) = w.deltaCC_glac;
+  FX(FX_GLACIER_MELT_ENERGY) = w.glacier_melt_energy;
 #undef FX
 }
 
 // ------------------------------------------------------------------------------------------------ HRU kernel
-template <int NN>
+template <int NN, bool GLAC>
 __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
   const int g = blockIdx.x * 64 + threadIdx.x;
   if (g >= a.nhru) return;
@@ -204,14 +214,17 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
   CellView cv{a.cell_params, a.ncell, c, o.Nnode, o.Nband};
   const double area = cv.band(CPB_AREAFRACT, band);
   const bool run = active && ((area > 0) || (is_glacier && o.GLACIER_DYNAMICS && area >= 0.0));
-  if (!run || is_glacier) {
-    // glacier HRUs are not handled by this kernel yet: flagged so that the caller sees it (never silently skipped)
+  // two instantiations share this body: GLAC = false handles ordinary HRUs (and writes the zero record of inactive
+  // ones), GLAC = true handles glacier HRUs; the domain numbering keeps either kind wave-uniform
+  if (is_glacier != GLAC && run) return;
+  if (!run) {
+    if (GLAC) return;
     fx[(size_t)FX_OUT_PREC * nh + g] = 0; fx[(size_t)FX_OUT_RAIN * nh + g] = 0; fx[(size_t)FX_OUT_SNOW * nh + g] = 0;
     fx[(size_t)FX_RUNOFF * nh + g] = 0; fx[(size_t)FX_BASEFLOW * nh + g] = 0;
     fx[(size_t)FX_EVAP0 * nh + g] = 0; fx[(size_t)FX_EVAP1 * nh + g] = 0; fx[(size_t)FX_EVAP2 * nh + g] = 0;
     fx[(size_t)FX_CANOPYEVAP * nh + g] = 0; fx[(size_t)FX_SNOW_VAPOR_FLUX * nh + g] = 0;
-    fx[(size_t)FX_SNOW_CANOPY_VAPOR_FLUX * nh + g] = 0;
-    a.hru_err[g] = (run && is_glacier) ? VICGPU_CELLERR_SOLVER : 0;
+    fx[(size_t)FX_SNOW_CANOPY_VAPOR_FLUX * nh + g] = 0; fx[(size_t)FX_GLAC_MASS_BALANCE * nh + g] = 0;
+    a.hru_err[g] = 0;
     return;
   }
   VegLib vl{a.veglib};
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
     }
   }
   top_layer_thermal_properties(cv, s3, w.moist, w.ice, w.so.kappa, w.so.Cs);
-  const double bare_albedo = vl.f(veg_idx, VL_ALBEDO + month - 1);
+  const double bare_albedo = GLAC ? cv.s(CP_GLAC_ALBEDO) : vl.f(veg_idx, VL_ALBEDO + month - 1);
 
   // aerodynamic resistances for the 6 PET surfaces and the current vegetation (full_energy.c:302-354)
   Vc aero_pet[NPET], Ra, U, disp, zref, z0;
@@ -279,8 +292,29 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
   for (int p = 0; p < NPET; p++) w.pot_evap[p] = 0;
 
   if (!(err & VICGPU_CELLERR_AERO)) {
-    const bool ok = surface_fluxes<NN>(o, cv, vl, s3, fc, dmy, veg_idx, band, is_art_bare, overstory, bare_albedo, ice0, moist0,
-                                       surf_atten, aero_pet, Ra, U, disp, zref, z0, root, w);
+    bool ok;
+    if constexpr (GLAC) {
+      GlacEnergy ge;
+      double nlu, nsu, sui;
+      ok = surface_fluxes_glac<NN>(o, cv, vl, s3, fc, dmy, veg_idx, band, bare_albedo, aero_pet, Ra, U, zref, z0, w, w.gl,
+                                   w.so.NetLongUnder, ge, nlu, nsu, sui);
+      // hru.energy = step_energy + step averages (surface_fluxes_glac.c:485-526)
+      SoilEnergy& so = w.so; SnowEnergy& se = w.se;
+      so.snow_flux = ge.snow_flux; so.grnd_flux = ge.grnd_flux; so.deltaH = 0; so.fusion = 0; so.LongUnderOut = ge.LongUnderOut;
+      so.AlbedoUnder = ge.AlbedoUnder; so.advected_sensible = ge.advected_sensible; so.advection = ge.advection;
+      so.deltaCC = ge.deltaCC; so.refreeze_energy = ge.refreeze_energy; so.error = ge.error; so.latent = ge.latent;
+      so.latent_sub = ge.latent_sub; so.sensible = ge.sensible; so.NetLongUnder = nlu; so.NetShortUnder = nsu; so.NetShortGrnd = 0;
+      se.canopy_advection = 0; se.canopy_latent = 0; se.canopy_latent_sub = 0; se.canopy_sensible = 0; se.canopy_refreeze = 0;
+      w.AlbedoOver_avg = 0; w.LongOverIn_avg = 0; w.NetLongOver_avg = 0; w.NetShortOver_avg = 0; w.ShortOverIn_avg = 0;
+      w.ShortUnderIn_avg = sui;
+      w.deltaCC_glac = ge.deltaCC_glac; w.glacier_flux = ge.glacier_flux; w.glacier_melt_energy = ge.glacier_melt_energy;
+      // accumulateGlacierMassBalance.c:13-67: the per-step += (the accumulation-window decision is driver state: the
+      // host makes cum_mass_balance valid when the window opens)
+      if (!isnan(w.gl.cum_mass_balance) && !isnan(w.gl.mass_balance)) w.gl.cum_mass_balance += w.gl.mass_balance;
+    } else {
+      ok = surface_fluxes<NN>(o, cv, vl, s3, fc, dmy, veg_idx, band, is_art_bare, overstory, bare_albedo, ice0, moist0, surf_atten,
+                              aero_pet, Ra, U, disp, zref, z0, root, w);
+    }
     if (!ok) err |= VICGPU_CELLERR_SOLVER;
   }
 
@@ -310,6 +344,7 @@ struct CArgs {
   const int* cell_off;
   const int* cell_list;
   const double* hpd;
+  const int* hpi_glac;   // row HPI_IS_GLACIER of the int parameter table
   const double* flux;
   const double* sd;
   const int* hru_err;
@@ -322,7 +357,7 @@ __global__ __launch_bounds__(256) void vic_cell_reduce(const CArgs a) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= a.ncell) return;
   const size_t nh = a.nhru, nc = a.ncell;
-  double op = 0, orn = 0, os = 0, ro = 0, bf = 0, ev = 0, swe = 0, sm0 = 0, sm1 = 0, sm2 = 0;
+  double op = 0, orn = 0, os = 0, ro = 0, bf = 0, ev = 0, swe = 0, sm0 = 0, sm1 = 0, sm2 = 0, gmb = 0;
   int err = 0;
   for (int k = a.cell_off[c]; k < a.cell_off[c + 1]; k++) {
     const int g = a.cell_list[k];
@@ -340,6 +375,7 @@ __global__ __launch_bounds__(256) void vic_cell_reduce(const CArgs a) {
     sm0 += a.sd[(size_t)SD_MOIST0 * nh + g] * Cv;
     sm1 += a.sd[(size_t)SD_MOIST1 * nh + g] * Cv;
     sm2 += a.sd[(size_t)SD_MOIST2 * nh + g] * Cv;
+    { double mb = a.flux[(size_t)FX_GLAC_MASS_BALANCE * nh + g]; if (a.hpi_glac[g] && !isnan(mb)) gmb += mb * Cv; }
     err |= a.hru_err[g];
   }
   a.cell_out[(size_t)CO_OUT_PREC * nc + c] = op;
@@ -353,6 +389,7 @@ __global__ __launch_bounds__(256) void vic_cell_reduce(const CArgs a) {
   a.accum[(size_t)CA_SOIL_MOIST_END0 * nc + c] = sm0;
   a.accum[(size_t)CA_SOIL_MOIST_END1 * nc + c] = sm1;
   a.accum[(size_t)CA_SOIL_MOIST_END2 * nc + c] = sm2;
+  a.accum[(size_t)CA_GLAC_MASS_BALANCE * nc + c] += gmb;
   a.accum[(size_t)CA_NSTEPS * nc + c] += 1.0;
   a.cell_err[c] |= err;
 }
@@ -378,6 +415,7 @@ struct vicgpu_ctx {
   int ev_used = 0;
   int write_fluxes = 1;
   int steps_done = 0;
+  bool any_glacier = false;
 };
 
 static void free_domain(vicgpu_ctx* c) {
@@ -389,9 +427,10 @@ static void free_domain(vicgpu_ctx* c) {
 }
 
 template <int NN>
-static hipError_t launch_hru(const KArgs& ka, hipStream_t st) {
+static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool any_glacier) {
   const int nblk = (ka.nhru + 63) / 64;
-  hipLaunchKernelGGL(vic_hru_step<NN>, dim3(nblk), dim3(64), 0, st, ka);
+  hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), 0, st, ka);
+  if (any_glacier) hipLaunchKernelGGL((vic_hru_step<NN, true>), dim3(nblk), dim3(64), 0, st, ka);
   return hipGetLastError();
 }
 
@@ -482,6 +521,8 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
   HIPCHK(c, hipSetDevice(c->device));
   free_domain(c);
   c->ncell = ncell; c->nhru = nhru;
+  c->any_glacier = false;
+  for (int g = 0; g < nhru; g++) if (hpi[(size_t)HPI_IS_GLACIER * nhru + g]) c->any_glacier = true;
   const size_t cp_n = (size_t)VICGPU_CP_NROW(c->opt.Nnode, c->opt.Nband) * ncell;
   const size_t sd_n = (size_t)VICGPU_SD_NROW(c->opt.Nnode) * nhru, si_n = (size_t)VICGPU_SI_NROW(c->opt.Nnode) * nhru;
   HIPCHK(c, hipMalloc(&c->d_cp, sizeof(double) * cp_n));
@@ -577,6 +618,7 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
   CArgs ca;
   ca.ncell = c->ncell; ca.nhru = c->nhru; ca.cell_off = c->d_cell_off; ca.cell_list = c->d_cell_list; ca.hpd = c->d_hpd;
+  ca.hpi_glac = c->d_hpi + (size_t)HPI_IS_GLACIER * c->nhru;
   ca.flux = c->d_flux; ca.sd = c->d_sd; ca.hru_err = c->d_hru_err; ca.cell_out = c->d_cell_out; ca.accum = c->d_accum;
   ca.cell_err = c->d_cell_err;
   for (int s = step0; s < step0 + nsteps; s++) {
@@ -587,9 +629,9 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
     ka.dmy.day = d[VIC_DMY_DAY]; ka.dmy.year = d[VIC_DMY_YEAR];
     HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0)], c->stream));
     hipError_t e;
-    if (c->o.Nnode == 3) e = launch_hru<3>(ka, c->stream);
-    else if (c->o.Nnode == 10) e = launch_hru<10>(ka, c->stream);
-    else e = launch_hru<VIC_MAX_NODES>(ka, c->stream);
+    if (c->o.Nnode == 3) e = launch_hru<3>(ka, c->stream, c->any_glacier);
+    else if (c->o.Nnode == 10) e = launch_hru<10>(ka, c->stream, c->any_glacier);
+    else e = launch_hru<VIC_MAX_NODES>(ka, c->stream, c->any_glacier);
     HIPCHK(c, e);
     HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0) + 1], c->stream));
     hipLaunchKernelGGL(vic_cell_reduce, dim3((c->ncell + 255) / 256), dim3(256), 0, c->stream, ca);
