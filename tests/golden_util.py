@@ -1,0 +1,33 @@
+import glob
+import os
+
+import numpy as np
+
+from vic_amd import abi, domain
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    """Returns (Domain rebuilt from the stored tables, npz dict)."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    opt = abi.default_options()
+    for k, v in zip(z["opt_names"], z["opt_values"]):
+        k = str(k)
+        setattr(opt, k, float(v) if k == "wind_h" else int(v))
+    d = domain.Domain()
+    d.opt = opt
+    d.veglib = np.ascontiguousarray(z["veglib"])
+    d.cell_params = np.ascontiguousarray(z["cell_params"])
+    d.hru_iparams = np.ascontiguousarray(z["hru_iparams"].astype(np.int32))
+    d.hru_dparams = np.ascontiguousarray(z["hru_dparams"])
+    d.cell_hru_offset = np.ascontiguousarray(z["cell_hru_offset"].astype(np.int32))
+    d.cell_hru_list = np.ascontiguousarray(z["cell_hru_list"].astype(np.int32))
+    d.init_moist = np.ascontiguousarray(z["init_moist"])
+    d.ncell = d.cell_params.shape[1]
+    d.nhru = d.hru_iparams.shape[1]
+    return d, z

@@ -1,0 +1,96 @@
+"""The CPU oracle (oracle/*.c) pinned against (i) committed golden vectors generated from the real reference build and
+(ii), when /root/reference is present, the reference build itself run side by side.  Bar: bit-exact (same libm, same
+operation order; the oracle is compiled with -ffp-contract=off like the reference's g++ -O2)."""
+import numpy as np
+import pytest
+
+from vic_amd import abi, domain
+from vic_amd.abi import C
+from tests.golden_util import golden_names, load_golden
+from tests.util import rel_diff, worst
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_reproduces_golden(name, oracle_lib):
+    d, z = load_golden(name)
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(z["sd0"], z["si0"].astype(np.int32))
+    f, sf, dmy = z["forcing"], z["snowflag"], z["dmy"]
+    want = {int(s): k for k, s in enumerate(z["steps"])}
+    rows = [r for r in range(C["FX_NROW"]) if r not in (C["FX_OUT_PREC"], C["FX_OUT_RAIN"], C["FX_OUT_SNOW"])]
+    for s in range(f.shape[0]):
+        fx, co, ce = orc.step(f[s], sf[s], dmy[s])
+        assert ce.sum() == 0
+        if s in want:
+            k = want[s]
+            sd, si = orc.get_state()
+            w1, m1 = worst(z["states_d"][k], sd, "SD_", floor=1e-12)
+            w2, m2 = worst(z["fluxes"][k][rows], fx[rows], "FX_", floor=1e-12)
+            w3, m3 = worst(z["cells"][k], co, "CO_", floor=1e-12)
+            assert w1 == 0.0, "step %d %s" % (s, m1)
+            assert w2 == 0.0, "step %d %s" % (s, m2)
+            assert w3 == 0.0, "step %d %s" % (s, m3)
+            assert np.array_equal(z["states_i"][k], si), "step %d int state" % s
+
+
+SIDE_BY_SIDE = [
+    ("quickflux", dict(FULL_ENERGY=1), "plain", 10, 3, False, 400, 70),
+    ("bands", dict(FULL_ENERGY=1, Nband=4), "plain", 6, 2, False, 300, 330),
+    ("wb_daily", dict(FULL_ENERGY=0, dt=24, snow_step=3), "plain", 8, 3, False, 365, 1),
+    ("wb_3hourly", dict(FULL_ENERGY=0, dt=3, snow_step=3), "plain", 6, 2, False, 400, 40),
+    ("frozen_fixed", dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=0), "fixed", 5, 3, False, 250, 280),
+    ("frozen_fixed_noflux", dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=12, NOFLUX=1, frozen_compat=0), "fixed", 4, 2, False, 150, 1),
+    ("frozen_compat", dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=1), "compat", 4, 2, False, 120, 330),
+    ("glacier", dict(FULL_ENERGY=1, Nband=3), "plain", 6, 2, True, 500, 120),
+    ("sntherm_sun1999", dict(FULL_ENERGY=1, SNOW_DENSITY=1, SNOW_ALBEDO=1), "plain", 6, 3, False, 300, 1),
+    ("vic412_ar410", dict(FULL_ENERGY=1, TEMP_TH_TYPE=0, AERO_RESIST_CANSNOW=3), "plain", 6, 3, False, 300, 350),
+]
+
+
+@pytest.mark.parametrize("case", SIDE_BY_SIDE, ids=[c[0] for c in SIDE_BY_SIDE])
+def test_oracle_vs_reference_side_by_side(case, oracle_lib, ref_available):
+    if not ref_available:
+        pytest.skip("reference build (oracle/_ref) not available")
+    name, kw, variant, ncell, ntile, glacier, nsteps, doy = case
+    opt = abi.default_options(**kw)
+    d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
+    ref = oracle_lib.RefModel(d, variant)
+    ref.init_state(f[0], dmy[0], d.init_moist)
+    sd0, si0 = ref.get_state()
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    rows = [r for r in range(C["FX_NROW"]) if r not in (C["FX_OUT_PREC"], C["FX_OUT_RAIN"], C["FX_OUT_SNOW"])]
+    for s in range(nsteps):
+        fr, cr, er = ref.step(f[s], sf[s], dmy[s])
+        fo, co, eo = orc.step(f[s], sf[s], dmy[s])
+        sr, ir = ref.get_state()
+        so, io = orc.get_state()
+        assert er.sum() == 0 and eo.sum() == 0
+        assert rel_diff(sr, so, 1e-12).max() == 0.0, "step %d %s" % (s, worst(sr, so, "SD_", 1e-12)[1])
+        assert rel_diff(fr[rows], fo[rows], 1e-12).max() == 0.0, "step %d %s" % (s, worst(fr[rows], fo[rows], "FX_", 1e-12)[1])
+        assert rel_diff(cr, co, 1e-12).max() == 0.0
+        assert np.array_equal(ir, io)
+    ref.close()
+
+
+def test_root_brent_known_cubic(oracle_lib):
+    """root_brent on a known cubic: x^3 - 2x - 5 has its real root at 2.0945514815423265."""
+    import ctypes
+    lib = ctypes.CDLL(oracle_lib.oracle_lib_path())
+    FN = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_double, ctypes.c_void_p)
+    lib.orc_root_brent.restype = ctypes.c_double
+    lib.orc_root_brent.argtypes = [ctypes.c_double, ctypes.c_double, FN, ctypes.c_void_p]
+    f = FN(lambda x, ctx: x ** 3 - 2 * x - 5)
+    r = lib.orc_root_brent(2.0, 3.0, f, None)
+    assert abs(r - 2.0945514815423265) < 2e-7
+    # root outside the initial bracket: the +-10 expansion (root_brent.c:183-190) finds it
+    r = lib.orc_root_brent(-1.0, 1.0, f, None)
+    assert abs(r - 2.0945514815423265) < 2e-7
+    # no sign change within 5 expansions -> ERROR (-999)
+    g = FN(lambda x, ctx: x * x + 1.0)
+    assert lib.orc_root_brent(-1.0, 1.0, g, None) == -999.0
+    # residual undefined (-999) on one side: bisection toward the valid side (root_brent.c:136-177)
+    h = FN(lambda x, ctx: -999.0 if x < -0.5 else x - 0.25)
+    r = lib.orc_root_brent(-2.0, 1.0, h, None)
+    assert abs(r - 0.25) < 2e-7
