@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Tuning aid: builds vic_amd/libvicgpu.so with -DVIC_PROF (s_memtime section timers + trip counters inside
+vic_hru_step), runs a few steps of a bench workload and prints where the wave cycles go.  The instrumented library
+replaces the production one: rebuild with `python vic_amd/build.py -f` afterwards (this script does it on exit).
+
+    python tools/prof_sections.py [--config cfg3] [--ncell 20000] [--steps 4]
+"""
+import argparse, ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CYC = {0: "kernel total", 1: "load + prepare + aero", 2: "solve_snow", 3: "calc_surf_energy_bal", 4: "  solve_T_profile (in 3)",
+       5: "compute_pot_evap", 6: "runoff", 7: "zwt + distribute_node_moisture", 8: "store", 9: "  snow_intercept (in 2)",
+       10: "  snow_melt (in 2)"}
+CNT = {0: "waves", 1: "lanes", 2: "sub-steps (wave)", 4: "profile trips (wave)", 5: "profile trips (lane)", 6: "profile Brent evals (lane)",
+       7: "SurfEB evals (wave)", 8: "SurfEB evals (lane)", 9: "SnowPackEB evals (wave)", 10: "SnowPackEB evals (lane)",
+       11: "CanopyEB evals (wave)", 12: "CanopyEB evals (lane)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--ncell", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--start-doy", type=int, default=-1)
+    ap.add_argument("--prebuilt", action="store_true", help="library was already built with -DVIC_PROF (GPU box)")
+    args = ap.parse_args()
+    from vic_amd import build as vb
+    if not args.prebuilt:
+        vb.build(force=True, extra=["-DVIC_PROF"])
+    import bench
+    from vic_amd import domain, init_state
+    from vic_amd.api import Model, load_library
+    cfg = bench.config(args.config)
+    opt = cfg["opt"]
+    doy = cfg["start_doy"] if args.start_doy < 0 else args.start_doy
+    d = domain.make_domain(args.ncell, opt, ntile=cfg["ntile"])
+    f, sf, dmy = domain.make_forcing(d, 0, args.steps + 1, start_doy=doy)
+    sd0, si0 = init_state.initial_state(d, f[0])
+    m = Model(d, device=0)
+    m.set_state(sd0, si0)
+    m.set_write_fluxes(False)
+    m.push_forcing(f, sf, dmy)
+    lib = load_library()
+    cyc = (ctypes.c_ulonglong * 32)()
+    cnt = (ctypes.c_ulonglong * 32)()
+    m.dist_prec(0, 1, sync=True)
+    lib.vicgpu_prof_read(cyc, cnt)
+    m.dist_prec(1, args.steps, sync=True)
+    ms, nl = m.last_kernel_ms()
+    assert lib.vicgpu_prof_read(cyc, cnt) == 0
+    cyc = np.array(cyc[:], dtype=np.float64)
+    cnt = np.array(cnt[:], dtype=np.float64)
+    print("kernel %.3f ms/launch over %d launches (instrumented build)" % (ms, nl))
+    tot = cyc[0]
+    for k, name in CYC.items():
+        print("  %-36s %14.0f cyc/wave  %5.1f %%" % (name, cyc[k] / max(cnt[0], 1), 100 * cyc[k] / tot))
+    for k, name in CNT.items():
+        print("  %-36s %14.0f" % (name, cnt[k]))
+    w = max(cnt[0], 1)
+    print("  per wave: sub-steps %.2f, SurfEB evals %.1f (lane mean %.1f), profile trips %.1f (lane mean %.1f, Brent evals/lane %.1f)" % (
+        cnt[2] / w, cnt[7] / w, cnt[8] / max(cnt[1], 1), cnt[4] / w, cnt[5] / max(cnt[1], 1), cnt[6] / max(cnt[1], 1)))
+    print("  per wave: SnowPackEB evals %.1f (lane mean %.1f), CanopyEB evals %.1f (lane mean %.1f)" % (
+        cnt[9] / w, cnt[10] / max(cnt[1], 1), cnt[11] / w, cnt[12] / max(cnt[1], 1)))
+    if not args.prebuilt:
+        vb.build(force=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -133,6 +133,7 @@ struct SnowPackEB {
          RefreezeEnergy, SensibleHeat, vapor_flux, blowing_flux, surface_flux;
 
   VIC_DEV double operator()(double TSurf) {
+    PROF_WAVE(9); PROF_LANE(10);
     const double TMean = TSurf, Density = RHO_W;
     if (Wind > 0.0) ra_used_surface = Ra / stability_correction(Z, 0.f, TMean, Tair, Wind, z0_snow);
     else ra_used_surface = HUGE_RESIST;
@@ -399,6 +400,7 @@ struct CanopyEB {
          VaporMassFlux;
 
   VIC_DEV double operator()(double Tfoliage) {
+    PROF_WAVE(11); PROF_LANE(12);
     double Tmp = Tfoliage + KELVIN;
     LongOverOut = STEFAN_B * (Tmp * Tmp * Tmp * Tmp);
     NetRadiation = NetShortOver + LongOverIn + LongUnderOut - 2 * (LongOverOut);

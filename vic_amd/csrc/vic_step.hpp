@@ -42,10 +42,12 @@ VIC_DEV SolveSnowOut solve_snow(const Opt& o, const CellView& cv, const VegLib& 
         const VegMonth vm = veg_month(vl, veg_idx, month);
         r.ShortUnderIn *= surf_atten;
         const double ShortOverIn = (1. - surf_atten) * fc.v(VIC_F_SHORTWAVE, hidx);
+        PROF_T0(t_si);
         if (!snow_intercept(o, cv, vm, s3, fc, hidx, (double)dt * SECPHOUR, r.Le, LongUnderOut, ShortOverIn, Tcanopy, BareAlbedo,
                             Ra, U, disp, zref, z0, ra_used, rainfall, snowfall, r.LongUnderIn, lmoist, lice, root, layerevap, snow,
                             se, vv))
           r.ok = false;
+        PROF_ADD(9, t_si);
         vv.throughfall = rainfall + snowfall;
         se.LongOverIn = fc.v(VIC_F_LONGWAVE, hidx);
       } else if (snowfall > 0. && vv.Wdew > 0.) {
@@ -74,9 +76,11 @@ VIC_DEV SolveSnowOut solve_snow(const Opt& o, const CellView& cv, const VegLib& 
         AlbedoUnder = snow.albedo;
       }
       r.NetShortSnow = (1.0 - AlbedoUnder) * (r.ShortUnderIn);
+      PROF_T0(t_sm);
       SnowMeltOut sm = snow_melt(o, r.Le, r.NetShortSnow, Tcanopy, Tgrnd, z0.v[SNOW_COVERED], Ra.v[SNOW_COVERED], ra_used[0], air_temp,
                                  (double)dt * SECPHOUR, fc.v(VIC_F_DENSITY, hidx), r.LongUnderIn, fc.v(VIC_F_PRESSURE, hidx), rainfall,
                                  snowfall, fc.v(VIC_F_VP, hidx), fc.v(VIC_F_VPD, hidx), U.v[SNOW_COVERED], zref.v[SNOW_COVERED], snow, se);
+      PROF_ADD(10, t_sm);
       if (!sm.ok) r.ok = false;
       r.melt = sm.melt; r.NetLongSnow = sm.NetLongSnow; r.OldTSurf = sm.OldTSurf;
       r.ppt += r.melt;
@@ -233,9 +237,12 @@ VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, 
     const double LongUnderOut = so.LongUnderOut;
     const double step_snow_surf_temp = snow.surf_temp, step_snow_depth = snow.depth;
 
+    PROF_T0(t_ss);
     SolveSnowOut ss = solve_snow(o, cv, vl, s3, fc, hidx, veg_idx, dmy, overstory, is_artificial_bare, BareAlbedo, LongUnderOut,
                                  Tcanopy, Tgrnd0, Tair, step_prec, AlbedoUnder_orig, Ra, U, disp, zref, z0, ra_used, coverage,
                                  surf_atten, snow_inflow, UnderStory, step_dt, w.moist, w.ice, root, layerevap, snow, se, vv_snow);
+    PROF_ADD(2, t_ss);
+    PROF_WAVE(2);
     if (!ss.ok) ok = false;
     delta_coverage = ss.delta_coverage;
     double step_melt = ss.melt, step_melt_energy = ss.melt_energy, step_ppt = ss.ppt;
@@ -247,6 +254,7 @@ VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, 
       step_melt_energy = 0;
     } else INCLUDE_SNOW = 0;
 
+    PROF_T0(t_sf);
     SurfOut sf = calc_surf_energy_bal<NN>(o, cv, vl, s3, fc, hidx, veg_idx, dmy.month, is_artificial_bare, overstory, ss.Le,
                                           ss.LongUnderIn, ss.NetLongSnow, ss.NetShortGrnd, ss.NetShortSnow, ss.OldTSurf, ss.ShortUnderIn,
                                           snow.albedo, se.latent, se.latent_sub, se.sensible, Tcanopy, VPDcanopy, VPcanopy,
@@ -254,6 +262,7 @@ VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, 
                                           (step_snow_depth + snow.depth) / 2., BareAlbedo, surf_atten, Ra, U, disp, zref, z0, ra_used,
                                           step_melt, step_ppt, ss.rainfall, root, INCLUDE_SNOW, UnderStory, step_dt, w.moist, w.ice,
                                           w.layer_T, layerevap, w.nd, so, snow, vv_soil);
+    PROF_ADD(3, t_sf);
     if (!sf.ok) ok = false;
     step_melt = sf.melt; step_ppt = sf.ppt;
     if (INCLUDE_SNOW) step_ppt += step_melt;
@@ -274,8 +283,10 @@ VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, 
       ra_s[p] = (stability_factor[0] == HUGE_RESIST) ? HUGE_RESIST : aero_pet_under_free[p].v[UnderStory] * stability_factor[0];
       ra_o[p] = (stability_factor[1] == HUGE_RESIST) ? HUGE_RESIST : aero_pet_under_free[p].v[CANOPY] * stability_factor[1];
     }
+    PROF_T0(t_pe);
     compute_pot_evap(o, vl, veg_idx, dmy.month, fc.v(VIC_F_SHORTWAVE, hidx), NetLongAtmos, Tair, VPDcanopy, cv.s(CP_ELEVATION), ra_s,
                      ra_o, pe);
+    PROF_ADD(5, t_pe);
 
     // store sub-step, surface_fluxes.c:699-816
     if (!is_artificial_bare) {
@@ -389,10 +400,14 @@ VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, 
 
   // runoff, surface_fluxes.c:941-948 (excess_moist is 0 after initialisation)
   w.inflow = ppt;
+  PROF_T0(t_ro);
   RunoffOut ro = runoff_step(o, cv, s3, w.moist, w.ice, w.evap, ppt);
   w.runoff = ro.runoff; w.baseflow = ro.baseflow; w.asat = ro.asat;
+  PROF_ADD(6, t_ro);
+  PROF_T0(t_zw);
   w.zwt = wrap_compute_zwt(cv, s3, w.moist);
   if (o.FULL_ENERGY || o.FROZEN_SOIL) distribute_node_moisture_properties<NN>(o, cv, s3, w.nd, w.moist);
+  PROF_ADD(7, t_zw);
   return ok;
 }
 

@@ -43,112 +43,176 @@ struct SoilThermalEqn {
   }
 };
 
-// Constant per-node inputs of the finite-difference profile solve, gathered once per calc_surf_energy_bal call:
-// the explicit scheme's A-E (frozen_soil.c:161-213) depend only on kappa, Cs, the node geometry and dt, so they are the
-// same for every residual evaluation of one Brent solve (upstream keeps them in static arrays for that reason;
-// SURVEY.md Finding 1.1).  fm/fb/fe are the freezing-curve parameters calc_soil_thermal_fluxes indexes per node:
-// in compat mode the LAYER arrays max_moist(mm)/bubble/expt followed by the node arrays (Finding 1.2).
+// ------------------------------------------------------------------------------------------------
+// Finite-difference soil temperature profile (solve_T_profile + calc_soil_thermal_fluxes, frozen_soil.c:105-225,
+// 305-505), laid out for a 64-lane wavefront.
+//
+// Node columns live in LDS as [node][lane] (ds_read/ds_write_b64 with a per-lane node index are bank-conflict
+// free: the two 32-lane halves never collide), so every lane can be at ITS OWN node: the reference's loop nest
+//      sweeps (<=1000) { nodes j { closed-form update | Brent (<=1000 residual evaluations with a pow) } }
+// is flattened into ONE wave loop in which each lane carries its own (sweep, node, Brent) state and advances by one
+// unit of work per trip.  A lane whose node is unfrozen moves to the next node while its neighbours iterate their
+// Brent; a lane that has converged waits only for the slowest lane's TOTAL work instead of for the slowest lane at
+// every node of every sweep.  Per lane the sequence of operations, and therefore the result, is the reference's.
+//
+// A-D of the explicit scheme (frozen_soil.c:161-213) depend only on kappa, Cs, the node geometry and dt, i.e. they are
+// the same for every residual evaluation of one Brent solve on Tsurf (upstream keeps them in static arrays for that
+// reason; SURVEY.md Finding 1.1), so they are built once per calc_surf_energy_bal call.  EI = E*(0-ice) serves the
+// closed-form update; E, ice, moist and the freezing-curve parameters of a frozen node are fetched when its Brent
+// starts (in compat mode the LAYER arrays max_moist(mm)/bubble/expt followed by the node arrays: Finding 1.2).
+// ------------------------------------------------------------------------------------------------
+constexpr int PROF_NARR = 7;   // T, T0, A, B, C, D, EI
+
 template <int NN>
-struct ProfileCoef {
-  double A[NN], B[NN], C[NN], D[NN], E[NN], fm[NN], fb[NN], fe[NN];
+constexpr size_t prof_lds_bytes() { return NN > 3 ? (size_t)(PROF_NARR * 8 + 4) * NN * 64 : 0; }
+
+template <int NN>
+struct ProfLds {
+  double* base;   // [PROF_NARR][NN][64] doubles of this wave
+  int* fbc;       // [NN][64] fallback counters of the current solve
+  int lane;
+  VIC_DEV double& T(int j) const { return base[(0 * NN + j) * 64 + lane]; }
+  VIC_DEV double& T0(int j) const { return base[(1 * NN + j) * 64 + lane]; }
+  VIC_DEV double& A(int j) const { return base[(2 * NN + j) * 64 + lane]; }
+  VIC_DEV double& B(int j) const { return base[(3 * NN + j) * 64 + lane]; }
+  VIC_DEV double& C(int j) const { return base[(4 * NN + j) * 64 + lane]; }
+  VIC_DEV double& D(int j) const { return base[(5 * NN + j) * 64 + lane]; }
+  VIC_DEV double& EI(int j) const { return base[(6 * NN + j) * 64 + lane]; }
+  VIC_DEV int& cnt(int j) const { return fbc[j * 64 + lane]; }
 };
 
 template <int NN>
-VIC_DEV void profile_coefficients(const Opt& o, const CellView& cv, const Soil3& s3, const Nodes<NN>& nd, double deltat, double Dp,
-                                  ProfileCoef<NN>& pc) {
+VIC_DEV double profile_E(const Opt& o, const CellView& cv, int j, int Nn, double Dp) {
+  if (!o.EXP_TRANS) {
+    double al = cv.node(CPN_ALPHA, j - 1);
+    return ICE_DENSITY * LF * al * al;
+  }
+  const double Bexp = log(Dp + 1.) / (double)(Nn - 1);
+  double z1 = cv.node(CPN_ZSUM, j) + 1;
+  return 4 * Bexp * Bexp * ICE_DENSITY * LF * z1 * z1;
+}
+
+template <int NN>
+VIC_DEV void profile_coefficients(const Opt& o, const CellView& cv, const Nodes<NN>& nd, double deltat, double Dp, const ProfLds<NN>& S) {
   const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
   const double Bexp = o.EXP_TRANS ? log(Dp + 1.) / (double)(Nn - 1) : 0.0;
 #pragma unroll
-  for (int j = 1; j < NN; j++) {
-    if (j < Nn - 1 || (o.NOFLUX && j == Nn - 1)) {
+  for (int j = 0; j < NN; j++) {
+    if (j < Nn) S.T0(j) = nd.T[j];
+    if (j >= 1 && (j < Nn - 1 || (o.NOFLUX && j == Nn - 1))) {
       const double kup = (j < Nn - 1) ? nd.kappa[(j + 1 < NN) ? j + 1 : j] : nd.kappa[j];
+      double E;
       if (!o.EXP_TRANS) {
         double al = cv.node(CPN_ALPHA, j - 1), be = cv.node(CPN_BETA, j - 1), ga = cv.node(CPN_GAMMA, j - 1);
-        pc.A[j] = nd.Cs[j] * al * al;
-        pc.B[j] = (kup - nd.kappa[j - 1]) * deltat;
-        pc.C[j] = 2 * deltat * nd.kappa[j] * al / ga;
-        pc.D[j] = 2 * deltat * nd.kappa[j] * al / be;
-        pc.E[j] = ICE_DENSITY * LF * al * al;
+        S.A(j) = nd.Cs[j] * al * al;
+        S.B(j) = (kup - nd.kappa[j - 1]) * deltat;
+        S.C(j) = 2 * deltat * nd.kappa[j] * al / ga;
+        S.D(j) = 2 * deltat * nd.kappa[j] * al / be;
+        E = ICE_DENSITY * LF * al * al;
       } else {
         double z1 = cv.node(CPN_ZSUM, j) + 1;
-        pc.A[j] = 4 * Bexp * Bexp * nd.Cs[j] * z1 * z1;
-        pc.B[j] = (kup - nd.kappa[j - 1]) * deltat;
-        pc.C[j] = 4 * deltat * nd.kappa[j];
-        pc.D[j] = 2 * deltat * nd.kappa[j] * Bexp;
-        pc.E[j] = 4 * Bexp * Bexp * ICE_DENSITY * LF * z1 * z1;
+        S.A(j) = 4 * Bexp * Bexp * nd.Cs[j] * z1 * z1;
+        S.B(j) = (kup - nd.kappa[j - 1]) * deltat;
+        S.C(j) = 4 * deltat * nd.kappa[j];
+        S.D(j) = 2 * deltat * nd.kappa[j] * Bexp;
+        E = 4 * Bexp * Bexp * ICE_DENSITY * LF * z1 * z1;
       }
-      if (o.frozen_compat) {
-        if (j < 3) { pc.fm[j] = s3.max_moist[j]; pc.fb[j] = cv.lay(CPL_BUBBLE, j); pc.fe[j] = cv.lay(CPL_EXPT, j); }
-        else { pc.fm[j] = cv.node(CPN_MAX_MOIST, j - 3); pc.fb[j] = cv.node(CPN_BUBBLE, j - 3); pc.fe[j] = cv.node(CPN_EXPT, j - 3); }
-      } else { pc.fm[j] = cv.node(CPN_MAX_MOIST, j); pc.fb[j] = cv.node(CPN_BUBBLE, j); pc.fe[j] = cv.node(CPN_EXPT, j); }
+      S.EI(j) = E * (0. - nd.ice[j]);
     }
   }
 }
 
-// solve_T_profile + calc_soil_thermal_fluxes (frozen_soil.c:105-225, 305-505): Gauss-Seidel sweeps of the explicit
-// finite-difference heat equation, Brent per frozen node.  T0[0] holds the trial surface temperature.
+// One profile solve; S.T0(0) holds the trial surface temperature.  Results: S.T(j), S.cnt(j), fbmask.
 template <int NN>
-VIC_DEV bool solve_T_profile(const Opt& o, bool frozen_on, const ProfileCoef<NN>& pc, const Nodes<NN>& nd, const double* T0,
-                             double* T, int* Tfbflag, int* Tfbcount) {
+VIC_DEV bool solve_T_profile(const Opt& o, bool frozen_on, const CellView& cv, const Soil3& s3, const Nodes<NN>& nd,
+                             const ProfLds<NN>& S, unsigned& fbmask) {
   const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
   const int MAXIT = 1000;
   const double threshold = 1.e-2;
-  double Tlast[NN];
+  const double Dp = cv.s(CP_DP);
 #pragma unroll
-  for (int j = 0; j < NN; j++) { T[j] = T0[j]; Tlast[j] = T0[j]; Tfbflag[j] = 0; Tfbcount[j] = 0; }
-  bool Done = false, ok = true;
-  int ItCount = 0;
-  const int jlast = o.NOFLUX ? Nn : Nn - 1;     // exclusive upper node of the sweep
-  while (!Done && ItCount < MAXIT) {
-    ItCount++;
-    double maxdiff = threshold;
-#pragma unroll 1
-    for (int j = 1; j < jlast; j++) {
+  for (int j = 0; j < NN; j++)
+    if (j < Nn) { S.T(j) = S.T0(j); S.cnt(j) = 0; }
+  fbmask = 0;
+  const int jlast = o.NOFLUX ? Nn : Nn - 1;     // exclusive upper node of a sweep
+  bool ok = true, converged = false;
+  bool done = (jlast <= 1);
+  if (done) converged = true;
+  int it = 1, j = 1;
+  double maxdiff = threshold, oldT = 0;
+  bool in_brent = false;
+  Brent br;
+  SoilThermalEqn eq;
+  br.phase = Brent::DONE;
+  while (!done) {
+    PROF_WAVE(4); PROF_LANE(5);
+    bool node_done = false;
+    double newT = 0;
+    if (!in_brent) {
+      oldT = S.T(j);
       const bool bottom = (j == Nn - 1);        // only reached with NOFLUX (frozen_soil.c:423-464)
-      const double oldT = T[j];
-      const double Tdn = bottom ? T[j] : T[j + 1], Tup = T[j - 1];
-      if (T[j] >= 0 || !frozen_on) {
-        if (!o.EXP_TRANS)
-          T[j] = (pc.A[j] * T0[j] + pc.B[j] * (Tdn - Tup) + pc.C[j] * Tdn + pc.D[j] * Tup + pc.E[j] * (0. - nd.ice[j]))
-                 / (pc.A[j] + pc.C[j] + pc.D[j]);
-        else
-          T[j] = (pc.A[j] * T0[j] + pc.B[j] * (Tdn - Tup) + pc.C[j] * (Tdn + Tup) - pc.D[j] * (Tdn - Tup) + pc.E[j] * (0. - nd.ice[j]))
-                 / (pc.A[j] + 2. * pc.C[j]);
+      const double Tdn = bottom ? oldT : S.T(j + 1), Tup = S.T(j - 1);
+      if (oldT >= 0 || !frozen_on) {
+        const double A = S.A(j), B = S.B(j), C = S.C(j), D = S.D(j);
+        if (!o.EXP_TRANS) newT = (A * S.T0(j) + B * (Tdn - Tup) + C * Tdn + D * Tup + S.EI(j)) / (A + C + D);
+        else newT = (A * S.T0(j) + B * (Tdn - Tup) + C * (Tdn + Tup) - D * (Tdn - Tup) + S.EI(j)) / (A + 2. * C);
+        node_done = true;
       } else {
-        SoilThermalEqn eq;
-        eq.TL = Tdn; eq.TU = Tup; eq.T0 = T0[j]; eq.moist = nd.moist[j]; eq.max_moist = pc.fm[j]; eq.bubble = pc.fb[j];
-        eq.expt = pc.fe[j]; eq.ice0 = nd.ice[j]; eq.A = pc.A[j]; eq.B = pc.B[j]; eq.C = pc.C[j]; eq.D = pc.D[j]; eq.E = pc.E[j];
+        eq.TL = Tdn; eq.TU = Tup; eq.T0 = S.T0(j); eq.moist = nd.moist[j]; eq.ice0 = nd.ice[j];
+        eq.A = S.A(j); eq.B = S.B(j); eq.C = S.C(j); eq.D = S.D(j); eq.E = profile_E<NN>(o, cv, j, Nn, Dp);
         eq.EXP_TRANS = o.EXP_TRANS; eq.node = j;
-        double r = root_brent(T0[j] - SOIL_DT, T0[j] + SOIL_DT, eq);
-        if (is_error(r)) {
-          if (o.TFALLBACK) { r = T0[j]; Tfbflag[j] = 1; Tfbcount[j]++; }
-          else ok = false;
-        }
-        T[j] = r;
+        if (o.frozen_compat) {
+          if (j < 3) { eq.max_moist = s3.max_moist[j]; eq.bubble = cv.lay(CPL_BUBBLE, j); eq.expt = cv.lay(CPL_EXPT, j); }
+          else { eq.max_moist = cv.node(CPN_MAX_MOIST, j - 3); eq.bubble = cv.node(CPN_BUBBLE, j - 3); eq.expt = cv.node(CPN_EXPT, j - 3); }
+        } else { eq.max_moist = cv.node(CPN_MAX_MOIST, j); eq.bubble = cv.node(CPN_BUBBLE, j); eq.expt = cv.node(CPN_EXPT, j); }
+        br.start(eq.T0 - SOIL_DT, eq.T0 + SOIL_DT);
+        in_brent = true;
       }
-      double diff = fabs(oldT - T[j]);
-      if (diff > maxdiff) maxdiff = diff;
     }
-    if (maxdiff <= threshold) Done = true;
-    if (!ok) break;
+    if (in_brent) {
+      PROF_LANE(6);
+      const double fx = eq(br.x);
+      br.advance(fx);
+      if (br.phase == Brent::DONE) {
+        double r = br.result;
+        if (is_error(r)) {
+          if (o.TFALLBACK) { r = eq.T0; fbmask |= (1u << j); S.cnt(j) += 1; }
+          else { ok = false; done = true; }
+        }
+        newT = r;
+        in_brent = false;
+        node_done = true;
+      }
+    }
+    if (node_done) {
+      S.T(j) = newT;
+      const double diff = fabs(oldT - newT);
+      if (diff > maxdiff) maxdiff = diff;
+      j++;
+      if (j >= jlast) {                           // end of a Gauss-Seidel sweep (frozen_soil.c:466)
+        if (maxdiff <= threshold) { converged = true; done = true; }
+        else if (it >= MAXIT) done = true;
+        else { it++; j = 1; maxdiff = threshold; }
+      }
+    }
   }
   if (!ok) return false;
-  if (o.TFALLBACK) {            // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T[j])
+  if (o.TFALLBACK) {            // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T[j]); Tlast == T0
 #pragma unroll 1
-    for (int j = 1; j < Nn - 1; j++) {
-      if (Tlast[j - 1] - Tlast[j] > 0 && Tlast[j + 1] - T[j] > 0 && (T[j - 1] - T[j]) - (Tlast[j - 1] - Tlast[j]) > 0
-          && (T[j + 1] - T[j]) - (Tlast[j + 1] - Tlast[j]) > 0) {
-        T[j] = 0.5 * (T[j - 1] + T[j + 1]);
-        Tfbflag[j] = 1;
-        Tfbcount[j]++;
+    for (int k = 1; k < Nn - 1; k++) {
+      const double Tk = S.T(k), Tm = S.T(k - 1), Tp = S.T(k + 1), Lk = S.T0(k), Lm = S.T0(k - 1), Lp = S.T0(k + 1);
+      if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
+        S.T(k) = 0.5 * (Tm + Tp);
+        fbmask |= (1u << k);
+        S.cnt(k) += 1;
       }
     }
   }
-  if (!Done) {
+  if (!converged) {
     if (o.TFALLBACK) {
-#pragma unroll
-      for (int j = 0; j < NN; j++)
-        if (j < Nn) { T[j] = T0[j]; Tfbflag[j] = 1; Tfbcount[j]++; }
+#pragma unroll 1
+      for (int k = 0; k < Nn; k++) { S.T(k) = S.T0(k); S.cnt(k) += 1; }
+      fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
     } else return false;
   }
   return true;
@@ -158,7 +222,8 @@ VIC_DEV bool solve_T_profile(const Opt& o, bool frozen_on, const ProfileCoef<NN>
 template <int NN>
 struct SurfEB {
   // constant inputs
-  const Opt* o; const CellView* cv; const Soil3* s3; const ProfileCoef<NN>* pc; const Nodes<NN>* nd;
+  const Opt* o; const CellView* cv; const Soil3* s3; const Nodes<NN>* nd;
+  ProfLds<NN> S;
   VegMonth vm;
   bool VEG, frozen_on, INCLUDE_SNOW, SNOWING, overstory;
   double delta_t, Cs1, Cs2, D1, D2, T1_old, T2, Ts_old, bubble, dp, expt, ice0, kappa1, kappa2, max_moist, moist, elevation,
@@ -169,9 +234,8 @@ struct SurfEB {
   const double* lmoist; const double* lice; const double* root;
   // state mutated by evaluations ("last evaluation wins")
   double Tsnow_surf;
-  double T0n[NN];                 // previous-step node temperatures; [0] is overwritten with the trial Ts (T_node[0] = TMean)
-  double Tnew[NN];
-  int Tfbflag[NN], Tfbcount[NN];
+  double Tnew2;                   // Tnew_node[2] of the last evaluation
+  unsigned fbmask;                // T_fbflag bits of the last profile solve
   double ra_used[2];
   VegVar* vv;
   double* layerevap;              // [3]
@@ -179,6 +243,7 @@ struct SurfEB {
   double NetLongBare, NetLongSnow, T1, deltaH, fusion, grnd_flux, latent_heat, latent_heat_sub, sensible_heat, snow_flux, error;
 
   VIC_DEV double operator()(double Ts) {
+    PROF_WAVE(7); PROF_LANE(8);
     const double TMean = Ts;
     const double Tmp = TMean + KELVIN;
     if (snow_coverage > 0 && !INCLUDE_SNOW) snow_flux = (kappa_snow * (Tsnow_surf - TMean));
@@ -190,11 +255,16 @@ struct SurfEB {
       if (o->GRND_FLUX_TYPE == VIC_GF_406) grnd_flux = att * (kappa1 / D1 * ((T1) - TMean));
       else grnd_flux = att * (kappa1 / D1 * ((T1) - TMean) + (kappa2 / D2 * (1. - exp(-D1 / dp)) * (T2 - (T1)))) / 2.;
     } else {
-      T0n[0] = TMean;
-      if (!solve_T_profile<NN>(*o, frozen_on, *pc, *nd, T0n, Tnew, Tfbflag, Tfbcount)) return ERROR_VAL;
-      T1 = Tnew[1];
+      if constexpr (NN > 3) {
+        PROF_T0(t_prof);
+        S.T0(0) = TMean;                                        // T_node[0] = TMean (func_surf_energy_bal.c:190)
+        if (!solve_T_profile<NN>(*o, frozen_on, *cv, *s3, *nd, S, fbmask)) return ERROR_VAL;
+        PROF_ADD(4, t_prof);
+        T1 = S.T(1);
+        Tnew2 = S.T(2);
+      }
       if (o->GRND_FLUX_TYPE == VIC_GF_406) grnd_flux = att * (kappa1 / D1 * ((T1) - TMean));
-      else grnd_flux = att * (kappa1 / D1 * ((T1) - TMean) + (kappa2 / D2 * (Tnew[2] - (T1)))) / 2.;
+      else grnd_flux = att * (kappa1 / D1 * ((T1) - TMean) + (kappa2 / D2 * (Tnew2 - (T1)))) / 2.;
     }
     if (o->GRND_FLUX_TYPE == VIC_GF_FULL) deltaH = att * (Cs1 * ((Ts_old + T1_old) - (TMean + T1)) * D1 / delta_t / 2.);
     else deltaH = (Cs1 * ((Ts_old + T1_old) - (TMean + T1)) * D1 / delta_t / 2.);
@@ -298,11 +368,14 @@ VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const Veg
   if (INCLUDE_SNOW || snow.swq == 0) { TmpNetLongSnow = NetLongSnow; TmpNetShortSnow = NetShortSnow; LongSnowIn = snow_coverage * LongUnderIn; }
   else { TmpNetShortSnow = 0.; TmpNetLongSnow = 0.; LongSnowIn = 0.; }
 
-  ProfileCoef<NN> pc;
-  if (!o.QUICK_FLUX) profile_coefficients<NN>(o, cv, s3, nd, delta_t, cv.s(CP_DP), pc);
-
   SurfEB<NN> eb;
-  eb.o = &o; eb.cv = &cv; eb.s3 = &s3; eb.pc = &pc; eb.nd = &nd; eb.vm = vm;
+  if constexpr (NN > 3) {
+    // one LDS slab per wave (block = one wave): node columns of the profile solver
+    extern __shared__ double vic_dyn_lds[];       // prof_lds_bytes<NN>() bytes, sized by the launch
+    eb.S.base = vic_dyn_lds; eb.S.fbc = reinterpret_cast<int*>(vic_dyn_lds + PROF_NARR * NN * 64); eb.S.lane = threadIdx.x & 63;
+    if (!o.QUICK_FLUX) profile_coefficients<NN>(o, cv, nd, delta_t, cv.s(CP_DP), eb.S);
+  } else { eb.S.base = nullptr; eb.S.fbc = nullptr; eb.S.lane = 0; }
+  eb.o = &o; eb.cv = &cv; eb.s3 = &s3; eb.nd = &nd; eb.vm = vm;
   eb.VEG = (!is_artificial_bare) && (vm.LAI > 0.0);
   eb.frozen_on = frozen_on; eb.INCLUDE_SNOW = INCLUDE_SNOW != 0; eb.SNOWING = snow.snow != 0; eb.overstory = overstory;
   eb.delta_t = delta_t; eb.Cs1 = e.Cs[0]; eb.Cs2 = e.Cs[1];
@@ -322,8 +395,7 @@ VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const Veg
   eb.z0_under = z0.v[UnderStory]; eb.ra_under = Ra.v[UnderStory];
   eb.lmoist = lmoist; eb.lice = lice; eb.root = root;
   eb.Tsnow_surf = snow.surf_temp;
-#pragma unroll
-  for (int n = 0; n < NN; n++) { eb.T0n[n] = nd.T[n]; eb.Tnew[n] = 0; eb.Tfbflag[n] = 0; eb.Tfbcount[n] = 0; }
+  eb.Tnew2 = 0; eb.fbmask = 0;
   eb.ra_used[0] = ra_used[0]; eb.ra_used[1] = ra_used[1];
   eb.vv = &vv; eb.layerevap = layerevap;
   eb.deltaCC = e.deltaCC; eb.refreeze_energy = e.refreeze_energy; eb.vapor_flux = snow.vapor_flux;
@@ -357,16 +429,27 @@ VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const Veg
   TmpNetLongSnow = eb.NetLongSnow;
   const double NetLongBare = eb.NetLongBare;
 
+  double Tnew[NN];
+  int cntnew[NN];
+#pragma unroll
+  for (int n = 0; n < NN; n++) { Tnew[n] = 0; cntnew[n] = 0; }
+  if constexpr (NN > 3) {
+    if (!o.QUICK_FLUX) {
+#pragma unroll
+      for (int n = 0; n < NN; n++)
+        if (n < Nn) { Tnew[n] = eb.S.T(n); cntnew[n] = eb.S.cnt(n); }
+    }
+  }
   if (o.QUICK_FLUX || !(o.FULL_ENERGY || frozen_on)) {
-    eb.Tnew[0] = Tsurf;
-    eb.Tnew[1] = eb.T1;
-    eb.Tnew[2] = eb.T2;
+    Tnew[0] = Tsurf;
+    Tnew[1] = eb.T1;
+    Tnew[2] = eb.T2;
   }
   // calc_layer_average_thermal_props (frozen_soil.c:12-103)
-  if (frozen_on) find_0_degree_fronts<NN>(o, cv, e, eb.Tnew);
+  if (frozen_on) find_0_degree_fronts<NN>(o, cv, e, Tnew);
   else e.Nfrost = 0;
 #pragma unroll
-  for (int n = 0; n < NN; n++) nd.T[n] = eb.Tnew[n];
+  for (int n = 0; n < NN; n++) nd.T[n] = Tnew[n];
   e.frozen = (e.Nfrost > 0) ? 1 : 0;
   if (o.QUICK_FLUX) estimate_layer_ice_content_quick_flux(o, cv, s3, nd.T[0], nd.T[1], lmoist, lice, lT);
   else if (!estimate_layer_ice_content<NN>(o, cv, s3, nd.T, lmoist, lice, lT)) out.ok = false;
@@ -431,7 +514,7 @@ VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const Veg
   e.Tsurf_fbflag = Tsurf_fbflag;
   e.Tsurf_fbcount += Tsurf_fbcount;
 #pragma unroll
-  for (int n = 0; n < NN; n++) { nd.fbflag[n] = eb.Tfbflag[n]; nd.fbcount[n] += eb.Tfbcount[n]; }
+  for (int n = 0; n < NN; n++) { nd.fbflag[n] = (eb.fbmask >> n) & 1u; nd.fbcount[n] += cntnew[n]; }
   out.Tsurf = Tsurf;
   return out;
 }

@@ -66,6 +66,23 @@ constexpr int PET_VEGNOCR = 5;
 // surface cases of VegConditions (VegConditions.h:4-20)
 enum { SNOW_FREE = 0, CANOPY = 1, SNOW_COVERED = 2, GLACIER_SURF = 3, NCASE = 4 };
 
+// Section timers / trip counters of the tuning build (-DVIC_PROF, tools/prof_sections.py); compiled out otherwise.
+#ifdef VIC_PROF
+__device__ unsigned long long vic_prof_cyc[32];
+__device__ unsigned long long vic_prof_cnt[32];
+VIC_DEV bool prof_leader() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
+#define PROF_T0(name) const long long name = (long long)__builtin_readcyclecounter()
+#define PROF_ADD(id, name) do { const long long _d = (long long)__builtin_readcyclecounter() - (name); \
+    if (prof_leader()) atomicAdd(&vic_prof_cyc[id], (unsigned long long)_d); } while (0)
+#define PROF_LANE(id) atomicAdd(&vic_prof_cnt[id], 1ull)
+#define PROF_WAVE(id) do { if (prof_leader()) atomicAdd(&vic_prof_cnt[id], 1ull); } while (0)
+#else
+#define PROF_T0(name) do { } while (0)
+#define PROF_ADD(id, name) do { } while (0)
+#define PROF_LANE(id) do { } while (0)
+#define PROF_WAVE(id) do { } while (0)
+#endif
+
 VIC_DEV bool is_error(double x) { return x <= -998.0; }   // RootBrent::resultIsError
 
 // ---- run-time options, passed by value to every kernel (lives in SGPRs / kernarg) ----

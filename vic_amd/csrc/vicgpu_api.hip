@@ -239,6 +239,7 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
     s3.Wpwp[l] = cv.lay(CPL_WPWP, l); s3.resid_moist[l] = cv.lay(CPL_RESID_MOIST, l);
   }
 
+  PROF_T0(t_kernel);
   HruWork<NN> w;
   load_state<NN>(a, g, w);
   w.snow.vapor_flux = 0.; w.snow.canopy_vapor_flux = 0.;                  // full_energy.c:261-262
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
 #pragma unroll
   for (int p = 0; p < NPET; p++) w.pot_evap[p] = 0;
 
+  PROF_ADD(1, t_kernel);
   if (!(err & VICGPU_CELLERR_AERO)) {
     bool ok;
     if constexpr (GLAC) {
@@ -333,9 +335,14 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
   finite = finite && isfinite(w.nd.T[0]) && isfinite(w.snow.swq);
   if (!finite) err |= VICGPU_CELLERR_NAN;
 
+  PROF_T0(t_store);
   store_state<NN>(a, g, w);
   store_flux<NN>(a, g, w);
   a.hru_err[g] = err;
+  PROF_ADD(8, t_store);
+  PROF_ADD(0, t_kernel);
+  PROF_WAVE(0);
+  PROF_LANE(1);
 }
 
 // ------------------------------------------------------------------------------------------------ cell kernel
@@ -429,12 +436,32 @@ static void free_domain(vicgpu_ctx* c) {
 template <int NN>
 static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool any_glacier) {
   const int nblk = (ka.nhru + 63) / 64;
-  hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), 0, st, ka);
-  if (any_glacier) hipLaunchKernelGGL((vic_hru_step<NN, true>), dim3(nblk), dim3(64), 0, st, ka);
+  const size_t lds = vic::prof_lds_bytes<NN>();    // node columns of the soil-profile solver, one slab per wave
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vic_hru_step<NN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vic_hru_step<NN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), lds, st, ka);
+  if (any_glacier) hipLaunchKernelGGL((vic_hru_step<NN, true>), dim3(nblk), dim3(64), lds, st, ka);
   return hipGetLastError();
 }
 
 extern "C" {
+
+#ifdef VIC_PROF
+// tuning build only (not part of include/vicgpu.h): read and clear the section counters
+int vicgpu_prof_read(unsigned long long* cyc, unsigned long long* cnt) {
+  if (hipMemcpyFromSymbol(cyc, HIP_SYMBOL(vic_prof_cyc), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(cnt, HIP_SYMBOL(vic_prof_cnt), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  unsigned long long z[32] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(vic_prof_cyc), z, sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(vic_prof_cnt), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 int vicgpu_abi_version(void) { return VICGPU_ABI_VERSION; }
 
@@ -629,7 +656,7 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
     ka.dmy.day = d[VIC_DMY_DAY]; ka.dmy.year = d[VIC_DMY_YEAR];
     HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0)], c->stream));
     hipError_t e;
-    if (c->o.Nnode == 3) e = launch_hru<3>(ka, c->stream, c->any_glacier);
+    if (c->o.Nnode == 3 && c->o.QUICK_FLUX) e = launch_hru<3>   /* <3> has no finite-difference profile solver */(ka, c->stream, c->any_glacier);
     else if (c->o.Nnode == 10) e = launch_hru<10>(ka, c->stream, c->any_glacier);
     else e = launch_hru<VIC_MAX_NODES>(ka, c->stream, c->any_glacier);
     HIPCHK(c, e);
