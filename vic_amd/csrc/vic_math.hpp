@@ -103,44 +103,45 @@ struct Brent {
   }
   VIC_DEV void fail() { result = ERROR_VAL; phase = DONE; }
 
-  // bracket-expansion loop head (root_brent.c:183): decides the next evaluation or enters the main loop
-  VIC_DEV void bracket_check() {
-    if ((fa * fb) >= 0 && j < MAXTRIES) {
-      if (which_err == 0) { a -= TSTEP; b += TSTEP; phase = EXP_A; x = a; }
-      else if (which_err == -1) { b += TSTEP; phase = EXP_ONE; x = b; }
-      else { a -= TSTEP; phase = EXP_ONE; x = a; }
-    } else if ((fa * fb) >= 0) fail();                                   // :244-248
-    else { fc = fb; i = 0; main_prestep(); }
-  }
-
-  // body of the main loop up to (not including) the evaluation at the new b (root_brent.c:258-322)
+  // body of the main loop up to (not including) the evaluation at the new b (root_brent.c:258-322).  Written with
+  // selects instead of branches: every lane of a wave executes the same instructions whichever of bisection, secant
+  // or inverse quadratic interpolation it takes (the unused quotients are computed and dropped), and each selected
+  // value is produced by the reference's own sequence of operations.
   VIC_DEV void main_prestep() {
-    if (fb * fc > 0) { c = a; fc = fa; d = b - a; e = d; }
-    if (fabs(fc) < fabs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
-    double tol = 2 * MACHEPS * fabs(b) + TTOL;
-    double m = 0.5 * (c - b);
-    if (fabs(m) <= tol || fb == 0) { result = b; phase = DONE; return; }
-    if (fabs(e) < tol || fabs(fa) <= fabs(fb)) { d = m; e = d; }
-    else {
-      double p, q, r, s = fb / fa;
-      if (a == c) { p = 2 * m * s; q = 1 - s; }
-      else {
-        q = fa / fc; r = fb / fc;
-        p = s * (2 * m * q * (q - r) - (b - a) * (r - 1));
-        q = (q - 1) * (r - 1) * (s - 1);
-      }
-      if (p > 0) q = -q; else p = -p;
-      s = e; e = d;
-      if ((2 * p) < (3 * m * q - fabs(tol * q)) && p < fabs(0.5 * s * q)) d = p / q;
-      else { d = m; e = d; }
+    const bool c1 = fb * fc > 0;
+    const double ba = b - a;
+    c = c1 ? a : c; fc = c1 ? fa : fc; d = c1 ? ba : d; e = c1 ? ba : e;
+    const bool c2 = fabs(fc) < fabs(fb);
+    {
+      const double oa = a, ob = b, oc = c, ofa = fa, ofb = fb, ofc = fc;
+      a = c2 ? ob : oa; b = c2 ? oc : ob; c = c2 ? ob : oc;
+      fa = c2 ? ofb : ofa; fb = c2 ? ofc : ofb; fc = c2 ? ofb : ofc;
     }
+    const double tol = 2 * MACHEPS * fabs(b) + TTOL;
+    const double m = 0.5 * (c - b);
+    if (fabs(m) <= tol || fb == 0) { result = b; phase = DONE; return; }
+    const bool bisect = fabs(e) < tol || fabs(fa) <= fabs(fb);
+    const double s = fb / fa, q1 = fa / fc, r = fb / fc;
+    const bool secant = (a == c);
+    double p = secant ? 2 * m * s : s * (2 * m * q1 * (q1 - r) - (b - a) * (r - 1));
+    double q = secant ? 1 - s : (q1 - 1) * (r - 1) * (s - 1);
+    const bool ppos = p > 0;
+    q = ppos ? -q : q;
+    p = ppos ? p : -p;
+    const double s2 = e;
+    const bool accept = !bisect && (2 * p) < (3 * m * q - fabs(tol * q)) && p < fabs(0.5 * s2 * q);
+    const double pq = p / q;
+    e = accept ? d : m;
+    d = accept ? pq : m;
     a = b; fa = fb;
     b += (fabs(d) > tol) ? d : ((m > 0) ? tol : -tol);
     phase = MAIN; x = b;
   }
 
-  // consume the residual at x and pick the next abscissa
+  // consume the residual at x and pick the next abscissa.  The bracket test (root_brent.c:183) and the main-loop body
+  // exist once: a wave whose lanes sit in different phases executes them together instead of one copy per phase.
   VIC_DEV void advance(double fx) {
+    int act = 0;   // 1: bracket test, 2: main-loop body
     switch (phase) {
       case EVAL_A0: fa = fx; phase = EVAL_B0; x = b; break;
       case EVAL_B0:
@@ -151,17 +152,17 @@ struct Brent {
           else { which_err = 1; last_good = a; last_bad = b; }
           c = 0.5 * (last_bad + last_good);
           k = 0; phase = SEARCH0; x = c;
-        } else { j = 0; bracket_check(); }
+        } else { j = 0; act = 1; }
         break;
       case SEARCH0:                                                                    // :152-175
         fc = fx;
         if (fc == ERROR_VAL && k < MAXITER) { last_bad = c; c = 0.5 * (last_bad + last_good); k++; x = c; break; }
         if (fc == ERROR_VAL) { fail(); break; }
         if (which_err == -1) { a = c; fa = fc; } else { b = c; fb = fc; }
-        j = 0; bracket_check();
+        j = 0; act = 1;
         break;
       case EXP_A: fa = fx; phase = EXP_B; x = b; break;                                // :186-189
-      case EXP_B: fb = fx; j++; bracket_check(); break;
+      case EXP_B: fb = fx; j++; act = 1; break;
       case EXP_ONE:                                                                    // :192-215
         if (which_err == -1) { fb = fx; if (fb == ERROR_VAL) { fail(); break; } last_good = a; }
         else { fa = fx; if (fa == ERROR_VAL) { fail(); break; } last_good = b; }
@@ -173,17 +174,26 @@ struct Brent {
         if (fc == ERROR_VAL && k < MAXITER) { last_bad = c; c = 0.5 * (last_bad + last_good); k++; x = c; break; }
         if (fc == ERROR_VAL) { fail(); break; }
         if (which_err == -1) { a = c; fa = fc; } else { b = c; fb = fc; }
-        j++; bracket_check();
+        j++; act = 1;
         break;
       case MAIN:                                                                       // :323-332
         fb = fx;
         if (fb == ERROR_VAL) { fail(); break; }
         i++;
         if (i >= MAXITER) { fail(); break; }
-        main_prestep();
+        act = 2;
         break;
       default: break;
     }
+    if (act == 1) {                      // bracket-expansion loop head (root_brent.c:183)
+      if ((fa * fb) >= 0 && j < MAXTRIES) {
+        if (which_err == 0) { a -= TSTEP; b += TSTEP; phase = EXP_A; x = a; }
+        else if (which_err == -1) { b += TSTEP; phase = EXP_ONE; x = b; }
+        else { a -= TSTEP; phase = EXP_ONE; x = a; }
+      } else if ((fa * fb) >= 0) fail();                                 // :244-248
+      else { fc = fb; i = 0; act = 2; }
+    }
+    if (act == 2) main_prestep();
   }
 };
 

@@ -1,0 +1,178 @@
+// vic_profile.hpp — the explicit soil temperature profile solve as a kernel of its own (device only, gfx950).
+//
+// solve_T_profile + calc_soil_thermal_fluxes (frozen_soil.c:105-225, 305-505): Gauss-Seidel sweeps over the thermal
+// nodes (<= 1000), each frozen node a Brent root find (root_brent.c, <= 1000 residual evaluations with a pow,
+// soil_thermal_eqn.c).  It is called once per residual evaluation of the Brent iteration on the surface temperature
+// (func_surf_energy_bal.c:190) and carries > 90 % of the arithmetic of a FROZEN_SOIL step, with a trip count that
+// differs from HRU to HRU by an order of magnitude.  It needs ~25 live doubles where the rest of the step needs
+// several hundred, so it runs here at many waves per SIMD, on a compacted work list, and balances its own load:
+//
+//   * one lane = one solve at a time; the loop nest is flattened into ONE wave loop in which every lane carries its
+//     own (sweep, node, Brent) state and advances by one unit of work per trip -- a lane on an unfrozen node moves on
+//     while its neighbours iterate their Brent;
+//   * the waves are persistent and pull work: a lane that has finished its solve waits until a quarter of the wave
+//     has (or nothing else can run), then the waiting lanes write their results and take the next entries of the
+//     work list with one wave-aggregated atomic.  All waves therefore drain together, and the rare, memory-bound
+//     write-back / load section runs for 16 lanes at a time instead of for one or two lanes on most trips;
+//   * node temperatures (the only per-lane-indexed data that changes) live in LDS as [node][lane]; the constant
+//     per-node records are read from the item block (vic_surface.hpp) when a lane enters a node.
+//
+// Per lane the sequence of floating-point operations, and therefore the result, is the reference's.
+#pragma once
+#include "vic_surface.hpp"
+
+namespace vic {
+
+struct PArgs {
+  const double* __restrict__ pin;    // item blocks [nhru][Nn][PREC]
+  const double* __restrict__ ts;     // trial surface temperature [nhru]
+  double* __restrict__ pout;         // [nhru][pout_stride(Nn)]: T[Nn], {fbmask | ok << 32}, int fallback counts [Nn]
+  const int* __restrict__ list;      // HRUs to solve
+  const int* __restrict__ count;     // number of list entries
+  int* next;                         // work-list cursor (zero at launch; the evaluation kernel clears it again)
+  int* count_zero;                   // counter of the list the following evaluation kernel appends to (cleared here)
+  int Nn, NOFLUX, EXP_TRANS, TFALLBACK;
+};
+
+__host__ __device__ inline int pout_stride(int Nn) { return Nn + 1 + (Nn + 1) / 2; }
+
+constexpr int PROFILE_GATE = 16;     // lanes that must be waiting before the write-back / fetch section runs
+
+template <int NN>
+__global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
+  __shared__ double Tl[NN * 64];      // current iterate  [node][lane]
+  __shared__ double T0l[NN * 64];     // previous step    [node][lane]
+  __shared__ int cntl[NN * 64];       // fallbacks of the current solve [node][lane]
+  const int lane = threadIdx.x;
+  const int n = *a.count;
+  if (blockIdx.x == 0 && lane == 0) *a.count_zero = 0;
+  if ((int)blockIdx.x * 64 >= n) return;           // more waves than work: nothing to pull
+
+  const int Nn = (NN == VIC_MAX_NODES) ? a.Nn : NN;
+  const int jlast = a.NOFLUX ? Nn : Nn - 1;     // exclusive upper node of a sweep
+  const int MAXIT = 1000;
+  const double threshold = 1.e-2;
+#define TL(j) Tl[(j) * 64 + lane]
+#define T0L(j) T0l[(j) * 64 + lane]
+#define CNT(j) cntl[(j) * 64 + lane]
+
+  enum { NODE = 1, BRENT = 2, FINISH = 3, IDLE = 4 };   // FINISH: solve done (or nothing yet), waiting at the gate
+  int mode = FINISH;
+  int hru = -1, it = 1, j = 1;
+  bool frozen_on = false, ok = true, converged = false;
+  unsigned fbmask = 0;
+  double maxdiff = threshold, oldT = 0;
+  const double* __restrict__ blk = a.pin;
+  Brent br;
+  SoilThermalEqn eq;
+  br.phase = Brent::DONE;
+
+  while (true) {
+    // ---- gate: write-back of finished solves + fetch of new items (wave-uniform branch)
+    const unsigned long long waiting = __ballot(mode == FINISH);
+    const unsigned long long running = __ballot(mode == NODE || mode == BRENT);
+    if (waiting == 0 && running == 0) break;             // every lane is IDLE
+    if (waiting != 0 && (__popcll(waiting) >= PROFILE_GATE || running == 0)) {
+      if (mode == FINISH) {
+        if (hru >= 0) {
+          if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T[j]); Tlast == T0
+#pragma unroll 1
+            for (int k = 1; k < Nn - 1; k++) {
+              const double Tk = TL(k), Tm = TL(k - 1), Tp = TL(k + 1), Lk = T0L(k), Lm = T0L(k - 1), Lp = T0L(k + 1);
+              if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
+                TL(k) = 0.5 * (Tm + Tp);
+                fbmask |= (1u << k);
+                CNT(k) += 1;
+              }
+            }
+          }
+          if (ok && !converged) {
+            if (a.TFALLBACK) {
+#pragma unroll 1
+              for (int k = 0; k < Nn; k++) { TL(k) = T0L(k); CNT(k) += 1; }
+              fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
+            } else ok = false;
+          }
+          double* __restrict__ out = a.pout + (size_t)hru * pout_stride(Nn);
+#pragma unroll
+          for (int k = 0; k < NN; k++)
+            if (k < Nn) out[k] = TL(k);
+          out[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
+          int* __restrict__ outc = reinterpret_cast<int*>(out + Nn + 1);
+#pragma unroll
+          for (int k = 0; k < NN; k++)
+            if (k < Nn) outc[k] = CNT(k);
+        }
+        // next item: one atomic for all waiting lanes
+        const int leader = __ffsll((long long)waiting) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(a.next, __popcll(waiting));
+        base = __builtin_amdgcn_readlane(base, leader);
+        const int slot = base + __popcll(waiting & ((1ull << lane) - 1ull));
+        if (slot < n) {
+          hru = a.list[slot];
+          blk = a.pin + (size_t)hru * Nn * PREC;
+          frozen_on = blk[PR_A] != 0.0;
+          const double Ts = a.ts[hru];
+#pragma unroll
+          for (int k = 0; k < NN; k++)
+            if (k < Nn) { const double t = (k == 0) ? Ts : blk[k * PREC + PR_T0]; T0L(k) = t; TL(k) = t; CNT(k) = 0; }
+          fbmask = 0; ok = true; it = 1; j = 1; maxdiff = threshold;
+          converged = (jlast <= 1);
+          mode = converged ? FINISH : NODE;
+        } else { hru = -1; mode = IDLE; }
+      }
+    }
+    // ---- one unit of work per lane
+    bool node_done = false;
+    double newT = 0;
+    if (mode == NODE) {
+      oldT = TL(j);
+      const bool bottom = (j == Nn - 1);        // only reached with NOFLUX (frozen_soil.c:423-464)
+      const double Tdn = bottom ? oldT : TL(j + 1), Tup = TL(j - 1);
+      const double* __restrict__ r = blk + j * PREC;
+      const double A = r[PR_A], B = r[PR_B], C = r[PR_C], D = r[PR_D], T0j = T0L(j);
+      if (oldT >= 0 || !frozen_on) {
+        const double EI = r[PR_EI];
+        if (!a.EXP_TRANS) newT = (A * T0j + B * (Tdn - Tup) + C * Tdn + D * Tup + EI) / (A + C + D);
+        else newT = (A * T0j + B * (Tdn - Tup) + C * (Tdn + Tup) - D * (Tdn - Tup) + EI) / (A + 2. * C);
+        node_done = true;
+      } else {
+        eq.TL = Tdn; eq.TU = Tup; eq.T0 = T0j; eq.moist = r[PR_MOIST]; eq.ice0 = r[PR_ICE];
+        eq.A = A; eq.B = B; eq.C = C; eq.D = D; eq.E = r[PR_E];
+        eq.max_moist = r[PR_MAXM]; eq.bubble = r[PR_BUB]; eq.expt = r[PR_EXPT];
+        eq.EXP_TRANS = a.EXP_TRANS; eq.node = j;
+        br.start(T0j - SOIL_DT, T0j + SOIL_DT);
+        mode = BRENT;
+      }
+    }
+    if (mode == BRENT) {
+      const double fx = eq(br.x);
+      br.advance(fx);
+      if (br.phase == Brent::DONE) {
+        double rt = br.result;
+        if (is_error(rt)) {
+          if (a.TFALLBACK) { rt = eq.T0; fbmask |= (1u << j); CNT(j) += 1; }
+          else { ok = false; mode = FINISH; }
+        }
+        if (mode == BRENT) { newT = rt; node_done = true; mode = NODE; }
+      }
+    }
+    if (node_done) {
+      TL(j) = newT;
+      const double diff = fabs(oldT - newT);
+      if (diff > maxdiff) maxdiff = diff;
+      j++;
+      if (j >= jlast) {                           // end of a Gauss-Seidel sweep (frozen_soil.c:466)
+        if (maxdiff <= threshold) { converged = true; mode = FINISH; }
+        else if (it >= MAXIT) mode = FINISH;
+        else { it++; j = 1; maxdiff = threshold; }
+      }
+    }
+  }
+#undef TL
+#undef T0L
+#undef CNT
+}
+
+}  // namespace vic

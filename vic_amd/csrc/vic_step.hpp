@@ -7,7 +7,7 @@ namespace vic {
 struct SolveSnowOut {
   double melt, Le, LongUnderIn, NetLongSnow, NetShortGrnd, NetShortSnow, ShortUnderIn, OldTSurf, delta_coverage, melt_energy,
          out_prec, out_rain, out_snow, ppt, rainfall, snowfall;
-  bool ok;
+  int ok, pad_;
 };
 
 // solve_snow (solve_snow.c:7-544), mu = 1, SPATIAL_SNOW off.  `coverage` and `surf_atten` persist across sub-steps in
@@ -171,232 +171,291 @@ struct HruWork {
   double deltaCC_glac, glacier_flux, glacier_melt_energy;
 };
 
+// Per-step constants of one HRU: the prologue of full_energy's HRU loop (full_energy.c:216-354)
+struct StepConst {
+  Vc aero_pet[NPET];     // aero_pet[p].v = { snowFree, canopy, snowCovered, - } resistances of PET type p
+  Vc Ra, U, disp, zref, z0;
+  double surf_atten, bare_albedo, ice0, moist0, root[3];
+  int veg_idx, band, is_art_bare, overstory;
+};
+
 // surface_fluxes (surface_fluxes.c:17-956) with CLOSE_ENERGY FALSE (both closure loops execute once), Ndist 1.
 // The reference's iter_* / step_* struct copies collapse to in-place updates of the snow side (se, snow, vv_snow) and
 // the soil side (so, nodes, layers, vv_soil); both sides start from last step's values as surface_fluxes.c:301-323 does.
+// The function is cut at the ground-surface root finder: sf_begin | { sf_sub_pre | solve | sf_sub_post }* | sf_end,
+// with everything that lives across the cut in SubLoop (whole step) and SubStep (one snow sub-step).
+struct SubLoop {
+  double snow_flux, coverage, last_snow_coverage, Tgrnd0, step_Wdew, AlbedoUnder_orig, snow_inflow, delta_coverage, surf_atten;
+  VegVar vv_snow, vv_soil;
+  int hidx, endhidx, step_dt, INCLUDE_SNOW, N_steps, ok;
+  double st_AlbedoOver, st_AlbedoUnder, st_AtmosLatent, st_AtmosLatentSub, st_AtmosSensible, st_LongOverIn,
+         st_LongUnderIn, st_LongUnderOut, st_NetLongAtmos, st_NetLongOver, st_NetLongUnder, st_NetShortAtmos,
+         st_NetShortGrnd, st_NetShortOver, st_NetShortUnder, st_ShortOverIn, st_ShortUnderIn,
+         st_advected_sensible, st_advection, st_canopy_advection, st_canopy_latent, st_canopy_latent_sub,
+         st_canopy_sensible, st_canopy_refreeze, st_deltaCC, st_deltaH, st_fusion, st_grnd_flux,
+         st_latent, st_latent_sub, st_melt_energy, st_refreeze_energy, st_sensible, st_snow_flux,
+         st_canopy_vapor_flux, st_melt, st_vapor_flux, st_blowing_flux, st_surface_flux, st_canopyevap,
+         st_throughfall, st_ppt, st_cond_surface, st_cond_overstory;
+  double st_layerevap[3], st_pot_evap[NPET];
+};
+
+struct SubStep {
+  SolveSnowOut ss;
+  double Tair, Tcanopy, VPcanopy, VPDcanopy, step_melt_energy;
+  int UnderStory, hidx;
+  SurfPost post;
+};
+
 template <int NN>
-VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, const Dmy& dmy,
-                            int veg_idx, int band, bool is_artificial_bare, bool overstory, double BareAlbedo, double ice0,
-                            double moist0, double surf_atten, const Vc* aero_pet_under_free, const Vc& Ra, const Vc& U,
-                            const Vc& disp, const Vc& zref, const Vc& z0, const double* root, HruWork<NN>& w) {
-  // aero_pet_under_free[p].v = { snowFree, canopy, snowCovered, - } resistances of PET type p (full_energy.c:302-354)
+VIC_DEV void sf_begin(const Opt& o, const Forcing& fc, const StepConst& C, HruWork<NN>& w, SubLoop& L) {
   const int NF = o.NF, NR = o.NR;
   Snow& snow = w.snow;
   SnowEnergy& se = w.se;
   SoilEnergy& so = w.so;
-  bool ok = true;
-
+  L.ok = 1;
+  L.surf_atten = C.surf_atten;        // solve_snow may reset it (no overstory); the change persists over the sub-steps
   so.advection = 0; so.deltaCC = 0; so.refreeze_energy = 0;           // energy->advection / deltaCC / refreeze_energy = 0
   se.advection = 0; se.deltaCC = 0; se.refreeze_energy = 0;
-  double snow_flux = (snow.swq > 0) ? so.snow_flux : -(so.grnd_flux + so.deltaH + so.fusion);
-  double coverage = snow.coverage;
-  VegVar vv_snow = w.vv, vv_soil = w.vv;
-  vv_snow.canopyevap = 0; vv_soil.canopyevap = 0; vv_snow.throughfall = 0; vv_soil.throughfall = 0;
+  L.snow_flux = (snow.swq > 0) ? so.snow_flux : -(so.grnd_flux + so.deltaH + so.fusion);
+  L.coverage = snow.coverage;
+  L.vv_snow = w.vv; L.vv_soil = w.vv;
+  L.vv_snow.canopyevap = 0; L.vv_soil.canopyevap = 0; L.vv_snow.throughfall = 0; L.vv_soil.throughfall = 0;
   w.evap[0] = w.evap[1] = w.evap[2] = 0;
-
-  int hidx, endhidx, step_dt;
-  if (snow.swq > 0 || snow.snow_canopy > 0 || fc.flag(NR)) { hidx = 0; endhidx = NF; step_dt = o.snow_step; }
-  else { hidx = NR; endhidx = NR + 1; step_dt = o.dt; }
-
-  double last_snow_coverage = snow.coverage;
-  const double Tgrnd0 = w.nd.T[0];   // Tgrnd = energy->T[0] reads the CALLER's struct (surface_fluxes.c:423): start-of-step value
-  double step_Wdew = w.vv.Wdew;
-  double AlbedoUnder_orig = so.AlbedoUnder;     // &energy->AlbedoUnder of the caller's struct (solve_snow's AlbedoUnder argument)
-  double snow_inflow = 0;
-  int INCLUDE_SNOW = 0, N_steps = 0;
-  double delta_coverage = 0;
-
-  double st_AlbedoOver = 0, st_AlbedoUnder = 0, st_AtmosLatent = 0, st_AtmosLatentSub = 0, st_AtmosSensible = 0, st_LongOverIn = 0,
-         st_LongUnderIn = 0, st_LongUnderOut = 0, st_NetLongAtmos = 0, st_NetLongOver = 0, st_NetLongUnder = 0, st_NetShortAtmos = 0,
-         st_NetShortGrnd = 0, st_NetShortOver = 0, st_NetShortUnder = 0, st_ShortOverIn = 0, st_ShortUnderIn = 0,
-         st_advected_sensible = 0, st_advection = 0, st_canopy_advection = 0, st_canopy_latent = 0, st_canopy_latent_sub = 0,
-         st_canopy_sensible = 0, st_canopy_refreeze = 0, st_deltaCC = 0, st_deltaH = 0, st_fusion = 0, st_grnd_flux = 0,
-         st_latent = 0, st_latent_sub = 0, st_melt_energy = 0, st_refreeze_energy = 0, st_sensible = 0, st_snow_flux = 0,
-         st_canopy_vapor_flux = 0, st_melt = 0, st_vapor_flux = 0, st_blowing_flux = 0, st_surface_flux = 0, st_canopyevap = 0,
-         st_throughfall = 0, st_ppt = 0, st_cond_surface = 0, st_cond_overstory = 0;
-  double st_layerevap[3] = {0, 0, 0}, st_pot_evap[NPET] = {0, 0, 0, 0, 0, 0};
-  const double ShortUnderIn_soil = 0;   // soil_energy.ShortUnderIn is never assigned for non-glacier HRUs: it keeps the 0 of
-                                        // initialize_model_state.c:278 through surface_fluxes.c:781,859
+  if (snow.swq > 0 || snow.snow_canopy > 0 || fc.flag(NR)) { L.hidx = 0; L.endhidx = NF; L.step_dt = o.snow_step; }
+  else { L.hidx = NR; L.endhidx = NR + 1; L.step_dt = o.dt; }
+  L.last_snow_coverage = snow.coverage;
+  L.Tgrnd0 = w.nd.T[0];   // Tgrnd = energy->T[0] reads the CALLER's struct (surface_fluxes.c:423): start-of-step value
+  L.step_Wdew = w.vv.Wdew;
+  L.AlbedoUnder_orig = so.AlbedoUnder;     // &energy->AlbedoUnder of the caller's struct (solve_snow's AlbedoUnder argument)
+  L.snow_inflow = 0;
+  L.INCLUDE_SNOW = 0; L.N_steps = 0;
+  L.delta_coverage = 0;
+  L.st_AlbedoOver = 0; L.st_AlbedoUnder = 0; L.st_AtmosLatent = 0; L.st_AtmosLatentSub = 0; L.st_AtmosSensible = 0; L.st_LongOverIn = 0;
+  L.st_LongUnderIn = 0; L.st_LongUnderOut = 0; L.st_NetLongAtmos = 0; L.st_NetLongOver = 0; L.st_NetLongUnder = 0; L.st_NetShortAtmos = 0;
+  L.st_NetShortGrnd = 0; L.st_NetShortOver = 0; L.st_NetShortUnder = 0; L.st_ShortOverIn = 0; L.st_ShortUnderIn = 0;
+  L.st_advected_sensible = 0; L.st_advection = 0; L.st_canopy_advection = 0; L.st_canopy_latent = 0; L.st_canopy_latent_sub = 0;
+  L.st_canopy_sensible = 0; L.st_canopy_refreeze = 0; L.st_deltaCC = 0; L.st_deltaH = 0; L.st_fusion = 0; L.st_grnd_flux = 0;
+  L.st_latent = 0; L.st_latent_sub = 0; L.st_melt_energy = 0; L.st_refreeze_energy = 0; L.st_sensible = 0; L.st_snow_flux = 0;
+  L.st_canopy_vapor_flux = 0; L.st_melt = 0; L.st_vapor_flux = 0; L.st_blowing_flux = 0; L.st_surface_flux = 0; L.st_canopyevap = 0;
+  L.st_throughfall = 0; L.st_ppt = 0; L.st_cond_surface = 0; L.st_cond_overstory = 0;
+#pragma unroll
+  for (int l = 0; l < 3; l++) L.st_layerevap[l] = 0;
+#pragma unroll
+  for (int p = 0; p < NPET; p++) L.st_pot_evap[p] = 0;
   w.out_prec = w.out_rain = w.out_snow = 0;
+}
 
-  do {
-    const double Tair = fc.v(VIC_F_AIR_TEMP, hidx) + cv.band(CPB_TFACTOR, band);
-    const double step_prec = fc.v(VIC_F_PREC, hidx) / 1.0 * cv.band(CPB_PFACTOR, band);
-    const double Tcanopy = Tair;
-    const double VPcanopy = fc.v(VIC_F_VP, hidx), VPDcanopy = fc.v(VIC_F_VPD, hidx);
-    snow.blowing_flux = 0.0;
-    int UnderStory = NCASE;
-    const double snow_grnd_flux = -snow_flux;
-    (void)snow_grnd_flux;                     // overwritten inside snow_melt
-    // per-iteration resets (surface_fluxes.c:501-532)
-    vv_snow.Wdew = step_Wdew; vv_soil.Wdew = step_Wdew;
-    vv_snow.canopyevap = 0; vv_soil.canopyevap = 0;
-    double layerevap[3] = {0, 0, 0};
-    double ra_used[2] = {w.aero_resist_surface, w.aero_resist_overstory};
-    snow.canopy_vapor_flux = 0; snow.vapor_flux = 0; snow.surface_flux = 0;
-    const double LongUnderOut = so.LongUnderOut;
-    const double step_snow_surf_temp = snow.surf_temp, step_snow_depth = snow.depth;
+// one snow sub-step up to the ground-surface root finder: solve_snow and the set-up of calc_surf_energy_bal
+// (surface_fluxes.c:494-601)
+template <int NN>
+VIC_DEV void sf_sub_pre(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, const Dmy& dmy,
+                        const StepConst& C, HruWork<NN>& w, SubLoop& L, SubStep& P, SurfEB& eb, SurfSolve& sv) {
+  Snow& snow = w.snow;
+  SnowEnergy& se = w.se;
+  SoilEnergy& so = w.so;
+  const int hidx = L.hidx;
+  const double Tair = fc.v(VIC_F_AIR_TEMP, hidx) + cv.band(CPB_TFACTOR, C.band);
+  const double step_prec = fc.v(VIC_F_PREC, hidx) / 1.0 * cv.band(CPB_PFACTOR, C.band);
+  const double Tcanopy = Tair;
+  const double VPcanopy = fc.v(VIC_F_VP, hidx), VPDcanopy = fc.v(VIC_F_VPD, hidx);
+  snow.blowing_flux = 0.0;
+  int UnderStory = NCASE;
+  // snow_grnd_flux = -snow_flux is overwritten inside snow_melt
+  // per-iteration resets (surface_fluxes.c:501-532)
+  L.vv_snow.Wdew = L.step_Wdew; L.vv_soil.Wdew = L.step_Wdew;
+  L.vv_snow.canopyevap = 0; L.vv_soil.canopyevap = 0;
+  double layerevap[3] = {0, 0, 0};
+  double ra_used[2] = {w.aero_resist_surface, w.aero_resist_overstory};
+  snow.canopy_vapor_flux = 0; snow.vapor_flux = 0; snow.surface_flux = 0;
+  const double LongUnderOut = so.LongUnderOut;
+  const double step_snow_surf_temp = snow.surf_temp, step_snow_depth = snow.depth;
 
-    PROF_T0(t_ss);
-    SolveSnowOut ss = solve_snow(o, cv, vl, s3, fc, hidx, veg_idx, dmy, overstory, is_artificial_bare, BareAlbedo, LongUnderOut,
-                                 Tcanopy, Tgrnd0, Tair, step_prec, AlbedoUnder_orig, Ra, U, disp, zref, z0, ra_used, coverage,
-                                 surf_atten, snow_inflow, UnderStory, step_dt, w.moist, w.ice, root, layerevap, snow, se, vv_snow);
-    PROF_ADD(2, t_ss);
-    PROF_WAVE(2);
-    if (!ss.ok) ok = false;
-    delta_coverage = ss.delta_coverage;
-    double step_melt = ss.melt, step_melt_energy = ss.melt_energy, step_ppt = ss.ppt;
+  PROF_T0(t_ss);
+  SolveSnowOut ss = solve_snow(o, cv, vl, s3, fc, hidx, C.veg_idx, dmy, C.overstory != 0, C.is_art_bare != 0, C.bare_albedo, LongUnderOut,
+                               Tcanopy, L.Tgrnd0, Tair, step_prec, L.AlbedoUnder_orig, C.Ra, C.U, C.disp, C.zref, C.z0, ra_used, L.coverage,
+                               L.surf_atten, L.snow_inflow, UnderStory, L.step_dt, w.moist, w.ice, C.root, layerevap, snow, se, L.vv_snow);
+  PROF_ADD(2, t_ss);
+  PROF_WAVE(2);
+  if (!ss.ok) L.ok = 0;
+  L.delta_coverage = ss.delta_coverage;
+  double step_melt_energy = ss.melt_energy;
 
-    if (isnan(snow.surf_temp) && snow.swq > 0) {                       // surface_fluxes.c:553-560 (UNSTABLE_SNOW is never set)
-      INCLUDE_SNOW = UnderStory + 1;
-      so.advection = se.advection;
-      snow.surf_temp = step_snow_surf_temp;
-      step_melt_energy = 0;
-    } else INCLUDE_SNOW = 0;
+  if (isnan(snow.surf_temp) && snow.swq > 0) {                       // surface_fluxes.c:553-560 (UNSTABLE_SNOW is never set)
+    L.INCLUDE_SNOW = UnderStory + 1;
+    so.advection = se.advection;
+    snow.surf_temp = step_snow_surf_temp;
+    step_melt_energy = 0;
+  } else L.INCLUDE_SNOW = 0;
 
-    PROF_T0(t_sf);
-    SurfOut sf = calc_surf_energy_bal<NN>(o, cv, vl, s3, fc, hidx, veg_idx, dmy.month, is_artificial_bare, overstory, ss.Le,
-                                          ss.LongUnderIn, ss.NetLongSnow, ss.NetShortGrnd, ss.NetShortSnow, ss.OldTSurf, ss.ShortUnderIn,
-                                          snow.albedo, se.latent, se.latent_sub, se.sensible, Tcanopy, VPDcanopy, VPcanopy,
-                                          delta_coverage, ice0, step_melt_energy, moist0, snow.coverage,
-                                          (step_snow_depth + snow.depth) / 2., BareAlbedo, surf_atten, Ra, U, disp, zref, z0, ra_used,
-                                          step_melt, step_ppt, ss.rainfall, root, INCLUDE_SNOW, UnderStory, step_dt, w.moist, w.ice,
-                                          w.layer_T, layerevap, w.nd, so, snow, vv_soil);
-    PROF_ADD(3, t_sf);
-    if (!sf.ok) ok = false;
-    step_melt = sf.melt; step_ppt = sf.ppt;
-    if (INCLUDE_SNOW) step_ppt += step_melt;
+  P.ss = ss; P.Tair = Tair; P.Tcanopy = Tcanopy; P.VPcanopy = VPcanopy; P.VPDcanopy = VPDcanopy;
+  P.step_melt_energy = step_melt_energy; P.UnderStory = UnderStory; P.hidx = hidx;
 
-    const double AtmosLatent = so.latent, AtmosLatentSub = so.latent_sub, AtmosSensible = so.sensible;
-    const double NetLongAtmos = so.NetLongUnder, NetShortAtmos = so.NetShortUnder;
-    w.Tcanopy = Tcanopy;
+  surf_setup<NN>(o, cv, vl, s3, fc, hidx, C.veg_idx, dmy.month, C.is_art_bare != 0, C.overstory != 0, ss.Le, ss.LongUnderIn,
+                 ss.NetLongSnow, ss.NetShortGrnd, ss.NetShortSnow, ss.OldTSurf, ss.ShortUnderIn, snow.albedo, se.latent, se.latent_sub,
+                 se.sensible, Tcanopy, VPDcanopy, VPcanopy, L.delta_coverage, C.ice0, step_melt_energy, C.moist0, snow.coverage,
+                 (step_snow_depth + snow.depth) / 2., C.bare_albedo, L.surf_atten, C.Ra, C.U, C.disp, C.zref, C.z0, ra_used, ss.melt, ss.ppt,
+                 ss.rainfall, C.root, L.INCLUDE_SNOW, UnderStory, L.step_dt, w.moist, w.ice, layerevap, w.nd, so, snow, L.vv_soil, eb,
+                 P.post, sv);
+}
 
-    // potential evaporation, surface_fluxes.c:658-693
-    double stability_factor[2], ra_s[NPET], ra_o[NPET], pe[NPET];
-    if (ra_used[0] == HUGE_RESIST) stability_factor[0] = HUGE_RESIST;
-    else stability_factor[0] = ra_used[0] / Ra.v[UnderStory];
-    if (ra_used[1] == ra_used[0]) stability_factor[1] = stability_factor[0];
-    else if (ra_used[1] == HUGE_RESIST) stability_factor[1] = HUGE_RESIST;
-    else stability_factor[1] = ra_used[1] / Ra.v[CANOPY];
+// the rest of the sub-step: calc_surf_energy_bal's bookkeeping, potential evaporation, sub-step sums
+// (surface_fluxes.c:601-816).  Tprof/cntprof/fbmask: the soil profile of the final evaluation (finite-difference path).
+template <int NN>
+VIC_DEV void sf_sub_post(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, const Dmy& dmy,
+                         const StepConst& C, HruWork<NN>& w, SubLoop& L, const SubStep& P, const SurfEB& eb, const SurfSolve& sv,
+                         const double* Tprof, const int* cntprof, unsigned fbmask) {
+  Snow& snow = w.snow;
+  SnowEnergy& se = w.se;
+  SoilEnergy& so = w.so;
+  const SolveSnowOut& ss = P.ss;
+  const int hidx = P.hidx, UnderStory = P.UnderStory;
+  const int INCLUDE_SNOW = L.INCLUDE_SNOW;
+  const double delta_coverage = L.delta_coverage;
+  const double step_melt_energy = P.step_melt_energy;
+  double layerevap[3], ra_used[2];
+  SurfOut sf = surf_post<NN>(o, cv, s3, P.post, eb, sv, Tprof, cntprof, fbmask, w.moist, w.ice, w.layer_T, layerevap, ra_used, w.nd,
+                             so, snow, L.vv_soil);
+  if (!sf.ok) L.ok = 0;
+  double step_melt = sf.melt, step_ppt = sf.ppt;
+  if (INCLUDE_SNOW) step_ppt += step_melt;
+
+  const double AtmosLatent = so.latent, AtmosLatentSub = so.latent_sub, AtmosSensible = so.sensible;
+  const double NetLongAtmos = so.NetLongUnder, NetShortAtmos = so.NetShortUnder;
+  w.Tcanopy = P.Tcanopy;
+
+  // potential evaporation, surface_fluxes.c:658-693
+  double stability_factor[2], ra_s[NPET], ra_o[NPET], pe[NPET];
+  if (ra_used[0] == HUGE_RESIST) stability_factor[0] = HUGE_RESIST;
+  else stability_factor[0] = ra_used[0] / C.Ra.v[UnderStory];
+  if (ra_used[1] == ra_used[0]) stability_factor[1] = stability_factor[0];
+  else if (ra_used[1] == HUGE_RESIST) stability_factor[1] = HUGE_RESIST;
+  else stability_factor[1] = ra_used[1] / C.Ra.v[CANOPY];
 #pragma unroll
-    for (int p = 0; p < NPET; p++) {
-      ra_s[p] = (stability_factor[0] == HUGE_RESIST) ? HUGE_RESIST : aero_pet_under_free[p].v[UnderStory] * stability_factor[0];
-      ra_o[p] = (stability_factor[1] == HUGE_RESIST) ? HUGE_RESIST : aero_pet_under_free[p].v[CANOPY] * stability_factor[1];
-    }
-    PROF_T0(t_pe);
-    compute_pot_evap(o, vl, veg_idx, dmy.month, fc.v(VIC_F_SHORTWAVE, hidx), NetLongAtmos, Tair, VPDcanopy, cv.s(CP_ELEVATION), ra_s,
-                     ra_o, pe);
-    PROF_ADD(5, t_pe);
+  for (int p = 0; p < NPET; p++) {
+    ra_s[p] = (stability_factor[0] == HUGE_RESIST) ? HUGE_RESIST : C.aero_pet[p].v[UnderStory] * stability_factor[0];
+    ra_o[p] = (stability_factor[1] == HUGE_RESIST) ? HUGE_RESIST : C.aero_pet[p].v[CANOPY] * stability_factor[1];
+  }
+  PROF_T0(t_pe);
+  compute_pot_evap(o, vl, C.veg_idx, dmy.month, fc.v(VIC_F_SHORTWAVE, hidx), NetLongAtmos, P.Tair, P.VPDcanopy, cv.s(CP_ELEVATION), ra_s,
+                   ra_o, pe);
+  PROF_ADD(5, t_pe);
 
-    // store sub-step, surface_fluxes.c:699-816
-    if (!is_artificial_bare) {
-      if (snow.snow) { st_throughfall += vv_snow.throughfall; st_canopyevap += vv_snow.canopyevap; vv_soil.Wdew = vv_snow.Wdew; }
-      else { st_throughfall += vv_soil.throughfall; st_canopyevap += vv_soil.canopyevap; vv_snow.Wdew = vv_soil.Wdew; }
-      step_Wdew = vv_soil.Wdew;
-    }
+  // store sub-step, surface_fluxes.c:699-816
+  if (!C.is_art_bare) {
+    if (snow.snow) { L.st_throughfall += L.vv_snow.throughfall; L.st_canopyevap += L.vv_snow.canopyevap; L.vv_soil.Wdew = L.vv_snow.Wdew; }
+    else { L.st_throughfall += L.vv_soil.throughfall; L.st_canopyevap += L.vv_soil.canopyevap; L.vv_snow.Wdew = L.vv_soil.Wdew; }
+    L.step_Wdew = L.vv_soil.Wdew;
+  }
 #pragma unroll
-    for (int l = 0; l < 3; l++) st_layerevap[l] += layerevap[l];
-    st_ppt += step_ppt;
-    st_cond_surface += (ra_used[0] > 0) ? 1 / ra_used[0] : HUGE_RESIST;
-    st_cond_overstory += (ra_used[1] > 0) ? 1 / ra_used[1] : HUGE_RESIST;
-    if (!is_artificial_bare) st_canopy_vapor_flux += snow.canopy_vapor_flux;
-    st_melt += step_melt;
-    st_vapor_flux += snow.vapor_flux;
-    st_surface_flux += snow.surface_flux;
-    st_blowing_flux += snow.blowing_flux;
-    w.out_prec += ss.out_prec * 1.0; w.out_rain += ss.out_rain * 1.0; w.out_snow += ss.out_snow * 1.0;
-    if (INCLUDE_SNOW) {
-      se.advected_sensible = so.advected_sensible;   // never written on the soil side: last step's average
-      se.advection = so.advection; se.deltaCC = so.deltaCC; se.latent = so.latent; se.latent_sub = so.latent_sub;
-      se.refreeze_energy = so.refreeze_energy; se.sensible = so.sensible; se.snow_flux = so.snow_flux;
-    }
-    st_AlbedoOver += se.AlbedoOver;
-    st_AlbedoUnder += so.AlbedoUnder;
-    st_AtmosLatent += AtmosLatent; st_AtmosLatentSub += AtmosLatentSub; st_AtmosSensible += AtmosSensible;
-    st_LongOverIn += se.LongOverIn;
-    st_LongUnderIn += ss.LongUnderIn;
-    st_LongUnderOut += so.LongUnderOut;
-    st_NetLongAtmos += NetLongAtmos;
-    st_NetLongOver += se.NetLongOver;
-    st_NetLongUnder += so.NetLongUnder;
-    st_NetShortAtmos += NetShortAtmos;
-    st_NetShortGrnd += ss.NetShortGrnd;
-    st_NetShortOver += se.NetShortOver;
-    st_NetShortUnder += so.NetShortUnder;
-    st_ShortOverIn += se.ShortOverIn;
-    st_ShortUnderIn += ShortUnderIn_soil;
-    st_canopy_advection += se.canopy_advection; st_canopy_latent += se.canopy_latent; st_canopy_latent_sub += se.canopy_latent_sub;
-    st_canopy_sensible += se.canopy_sensible; st_canopy_refreeze += se.canopy_refreeze;
-    st_deltaH += so.deltaH; st_fusion += so.fusion; st_grnd_flux += so.grnd_flux; st_latent += so.latent;
-    st_latent_sub += so.latent_sub; st_melt_energy += step_melt_energy; st_sensible += so.sensible;
-    if (snow.swq == 0 && INCLUDE_SNOW) {
-      if (last_snow_coverage == 0) last_snow_coverage = 1;             // pointer test always true, SURVEY.md Appendix C #5
-      st_advected_sensible += se.advected_sensible * last_snow_coverage;
-      st_advection += se.advection * last_snow_coverage;
-      st_deltaCC += se.deltaCC * last_snow_coverage;
-      st_snow_flux += so.snow_flux * last_snow_coverage;
-      st_refreeze_energy += se.refreeze_energy * last_snow_coverage;
-    } else if (snow.snow || INCLUDE_SNOW) {
-      const double cf = (snow.coverage + delta_coverage);
-      st_advected_sensible += se.advected_sensible * cf;
-      st_advection += se.advection * cf;
-      st_deltaCC += se.deltaCC * cf;
-      st_snow_flux += so.snow_flux * cf;
-      st_refreeze_energy += se.refreeze_energy * cf;
-    }
+  for (int l = 0; l < 3; l++) L.st_layerevap[l] += layerevap[l];
+  L.st_ppt += step_ppt;
+  L.st_cond_surface += (ra_used[0] > 0) ? 1 / ra_used[0] : HUGE_RESIST;
+  L.st_cond_overstory += (ra_used[1] > 0) ? 1 / ra_used[1] : HUGE_RESIST;
+  if (!C.is_art_bare) L.st_canopy_vapor_flux += snow.canopy_vapor_flux;
+  L.st_melt += step_melt;
+  L.st_vapor_flux += snow.vapor_flux;
+  L.st_surface_flux += snow.surface_flux;
+  L.st_blowing_flux += snow.blowing_flux;
+  w.out_prec += ss.out_prec * 1.0; w.out_rain += ss.out_rain * 1.0; w.out_snow += ss.out_snow * 1.0;
+  if (INCLUDE_SNOW) {
+    se.advected_sensible = so.advected_sensible;   // never written on the soil side: last step's average
+    se.advection = so.advection; se.deltaCC = so.deltaCC; se.latent = so.latent; se.latent_sub = so.latent_sub;
+    se.refreeze_energy = so.refreeze_energy; se.sensible = so.sensible; se.snow_flux = so.snow_flux;
+  }
+  L.st_AlbedoOver += se.AlbedoOver;
+  L.st_AlbedoUnder += so.AlbedoUnder;
+  L.st_AtmosLatent += AtmosLatent; L.st_AtmosLatentSub += AtmosLatentSub; L.st_AtmosSensible += AtmosSensible;
+  L.st_LongOverIn += se.LongOverIn;
+  L.st_LongUnderIn += ss.LongUnderIn;
+  L.st_LongUnderOut += so.LongUnderOut;
+  L.st_NetLongAtmos += NetLongAtmos;
+  L.st_NetLongOver += se.NetLongOver;
+  L.st_NetLongUnder += so.NetLongUnder;
+  L.st_NetShortAtmos += NetShortAtmos;
+  L.st_NetShortGrnd += ss.NetShortGrnd;
+  L.st_NetShortOver += se.NetShortOver;
+  L.st_NetShortUnder += so.NetShortUnder;
+  L.st_ShortOverIn += se.ShortOverIn;
+  L.st_ShortUnderIn += 0.0;   // soil_energy.ShortUnderIn is never assigned for non-glacier HRUs: it keeps the 0 of
+                              // initialize_model_state.c:278 through surface_fluxes.c:781,859
+  L.st_canopy_advection += se.canopy_advection; L.st_canopy_latent += se.canopy_latent; L.st_canopy_latent_sub += se.canopy_latent_sub;
+  L.st_canopy_sensible += se.canopy_sensible; L.st_canopy_refreeze += se.canopy_refreeze;
+  L.st_deltaH += so.deltaH; L.st_fusion += so.fusion; L.st_grnd_flux += so.grnd_flux; L.st_latent += so.latent;
+  L.st_latent_sub += so.latent_sub; L.st_melt_energy += step_melt_energy; L.st_sensible += so.sensible;
+  if (snow.swq == 0 && INCLUDE_SNOW) {
+    if (L.last_snow_coverage == 0) L.last_snow_coverage = 1;           // pointer test always true, SURVEY.md Appendix C #5
+    L.st_advected_sensible += se.advected_sensible * L.last_snow_coverage;
+    L.st_advection += se.advection * L.last_snow_coverage;
+    L.st_deltaCC += se.deltaCC * L.last_snow_coverage;
+    L.st_snow_flux += so.snow_flux * L.last_snow_coverage;
+    L.st_refreeze_energy += se.refreeze_energy * L.last_snow_coverage;
+  } else if (snow.snow || INCLUDE_SNOW) {
+    const double cf = (snow.coverage + delta_coverage);
+    L.st_advected_sensible += se.advected_sensible * cf;
+    L.st_advection += se.advection * cf;
+    L.st_deltaCC += se.deltaCC * cf;
+    L.st_snow_flux += so.snow_flux * cf;
+    L.st_refreeze_energy += se.refreeze_energy * cf;
+  }
 #pragma unroll
-    for (int p = 0; p < NPET; p++) st_pot_evap[p] += pe[p];
-    N_steps++;
-    hidx += 1;
-  } while (hidx < endhidx);
+  for (int p = 0; p < NPET; p++) L.st_pot_evap[p] += pe[p];
+  L.N_steps++;
+  L.hidx += 1;
+}
 
-  const double N = (double)N_steps;
-  snow.vapor_flux = st_vapor_flux; snow.blowing_flux = st_blowing_flux; snow.surface_flux = st_surface_flux;
-  snow.canopy_vapor_flux = st_canopy_vapor_flux; snow.melt = st_melt;
-  double ppt = st_ppt;
+// step averages and runoff (surface_fluxes.c:818-948)
+template <int NN>
+VIC_DEV bool sf_end(const Opt& o, const CellView& cv, const Soil3& s3, const StepConst& C, HruWork<NN>& w, SubLoop& L) {
+  Snow& snow = w.snow;
+  SnowEnergy& se = w.se;
+  SoilEnergy& so = w.so;
+  const double N = (double)L.N_steps;
+  snow.vapor_flux = L.st_vapor_flux; snow.blowing_flux = L.st_blowing_flux; snow.surface_flux = L.st_surface_flux;
+  snow.canopy_vapor_flux = L.st_canopy_vapor_flux; snow.melt = L.st_melt;
+  double ppt = L.st_ppt;
 
   // *energy = soil_energy, then the step averages (surface_fluxes.c:842-881)
-  w.AlbedoOver_avg = st_AlbedoOver / N;
-  so.AlbedoUnder = st_AlbedoUnder / N;
-  w.AtmosLatent = st_AtmosLatent / N; w.AtmosLatentSub = st_AtmosLatentSub / N; w.AtmosSensible = st_AtmosSensible / N;
-  w.LongOverIn_avg = st_LongOverIn / N;
-  w.LongUnderIn = st_LongUnderIn / N;
-  so.LongUnderOut = st_LongUnderOut / N;
-  w.NetLongAtmos = st_NetLongAtmos / N;
-  w.NetLongOver_avg = st_NetLongOver / N;
-  so.NetLongUnder = st_NetLongUnder / N;
-  w.NetShortAtmos = st_NetShortAtmos / N;
-  so.NetShortGrnd = st_NetShortGrnd / N;
-  w.NetShortOver_avg = st_NetShortOver / N;
-  so.NetShortUnder = st_NetShortUnder / N;
-  w.ShortOverIn_avg = st_ShortOverIn / N;
-  w.ShortUnderIn_avg = st_ShortUnderIn / N;
-  so.advected_sensible = st_advected_sensible / N;
-  se.canopy_advection = st_canopy_advection / N; se.canopy_latent = st_canopy_latent / N;
-  se.canopy_latent_sub = st_canopy_latent_sub / N; se.canopy_refreeze = st_canopy_refreeze / N;
-  se.canopy_sensible = st_canopy_sensible / N;
-  so.deltaH = st_deltaH / N; so.fusion = st_fusion / N; so.grnd_flux = st_grnd_flux / N; so.latent = st_latent / N;
-  so.latent_sub = st_latent_sub / N; so.melt_energy = st_melt_energy / N; so.sensible = st_sensible / N;
-  if (snow.snow || INCLUDE_SNOW) {
-    so.advection = st_advection / N; so.deltaCC = st_deltaCC / N; so.refreeze_energy = st_refreeze_energy / N;
-    so.snow_flux = st_snow_flux / N;
+  w.AlbedoOver_avg = L.st_AlbedoOver / N;
+  so.AlbedoUnder = L.st_AlbedoUnder / N;
+  w.AtmosLatent = L.st_AtmosLatent / N; w.AtmosLatentSub = L.st_AtmosLatentSub / N; w.AtmosSensible = L.st_AtmosSensible / N;
+  w.LongOverIn_avg = L.st_LongOverIn / N;
+  w.LongUnderIn = L.st_LongUnderIn / N;
+  so.LongUnderOut = L.st_LongUnderOut / N;
+  w.NetLongAtmos = L.st_NetLongAtmos / N;
+  w.NetLongOver_avg = L.st_NetLongOver / N;
+  so.NetLongUnder = L.st_NetLongUnder / N;
+  w.NetShortAtmos = L.st_NetShortAtmos / N;
+  so.NetShortGrnd = L.st_NetShortGrnd / N;
+  w.NetShortOver_avg = L.st_NetShortOver / N;
+  so.NetShortUnder = L.st_NetShortUnder / N;
+  w.ShortOverIn_avg = L.st_ShortOverIn / N;
+  w.ShortUnderIn_avg = L.st_ShortUnderIn / N;
+  so.advected_sensible = L.st_advected_sensible / N;
+  se.canopy_advection = L.st_canopy_advection / N; se.canopy_latent = L.st_canopy_latent / N;
+  se.canopy_latent_sub = L.st_canopy_latent_sub / N; se.canopy_refreeze = L.st_canopy_refreeze / N;
+  se.canopy_sensible = L.st_canopy_sensible / N;
+  so.deltaH = L.st_deltaH / N; so.fusion = L.st_fusion / N; so.grnd_flux = L.st_grnd_flux / N; so.latent = L.st_latent / N;
+  so.latent_sub = L.st_latent_sub / N; so.melt_energy = L.st_melt_energy / N; so.sensible = L.st_sensible / N;
+  if (snow.snow || L.INCLUDE_SNOW) {
+    so.advection = L.st_advection / N; so.deltaCC = L.st_deltaCC / N; so.refreeze_energy = L.st_refreeze_energy / N;
+    so.snow_flux = L.st_snow_flux / N;
   }
 
-  if (!is_artificial_bare) {
-    w.vv.throughfall = st_throughfall;
-    w.vv.canopyevap = st_canopyevap;
-    w.vv.Wdew = snow.snow ? vv_snow.Wdew : vv_soil.Wdew;
+  if (!C.is_art_bare) {
+    w.vv.throughfall = L.st_throughfall;
+    w.vv.canopyevap = L.st_canopyevap;
+    w.vv.Wdew = snow.snow ? L.vv_snow.Wdew : L.vv_soil.Wdew;
   }
 #pragma unroll
-  for (int l = 0; l < 3; l++) w.evap[l] = st_layerevap[l];
-  if (st_cond_surface > 0 && st_cond_surface < HUGE_RESIST) w.aero_resist_surface = 1 / (st_cond_surface / N);
-  else if (st_cond_surface >= HUGE_RESIST) w.aero_resist_surface = 0;
+  for (int l = 0; l < 3; l++) w.evap[l] = L.st_layerevap[l];
+  if (L.st_cond_surface > 0 && L.st_cond_surface < HUGE_RESIST) w.aero_resist_surface = 1 / (L.st_cond_surface / N);
+  else if (L.st_cond_surface >= HUGE_RESIST) w.aero_resist_surface = 0;
   else w.aero_resist_surface = HUGE_RESIST;
-  if (st_cond_overstory > 0 && st_cond_overstory < HUGE_RESIST) w.aero_resist_overstory = 1 / (st_cond_overstory / N);
-  else if (st_cond_overstory >= HUGE_RESIST) w.aero_resist_overstory = 0;
+  if (L.st_cond_overstory > 0 && L.st_cond_overstory < HUGE_RESIST) w.aero_resist_overstory = 1 / (L.st_cond_overstory / N);
+  else if (L.st_cond_overstory >= HUGE_RESIST) w.aero_resist_overstory = 0;
   else w.aero_resist_overstory = HUGE_RESIST;
 #pragma unroll
-  for (int p = 0; p < NPET; p++) w.pot_evap[p] = st_pot_evap[p] / N;
+  for (int p = 0; p < NPET; p++) w.pot_evap[p] = L.st_pot_evap[p] / N;
 
   // runoff, surface_fluxes.c:941-948 (excess_moist is 0 after initialisation)
   w.inflow = ppt;
@@ -408,7 +467,29 @@ VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, 
   w.zwt = wrap_compute_zwt(cv, s3, w.moist);
   if (o.FULL_ENERGY || o.FROZEN_SOIL) distribute_node_moisture_properties<NN>(o, cv, s3, w.nd, w.moist);
   PROF_ADD(7, t_zw);
-  return ok;
+  return L.ok != 0;
+}
+
+// the whole of surface_fluxes in one lane (QUICK_FLUX: no soil-profile solve, the root finder is a short lane loop)
+template <int NN>
+VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, const Dmy& dmy,
+                            const StepConst& C, HruWork<NN>& w) {
+  SubLoop L;
+  sf_begin<NN>(o, fc, C, w, L);
+  do {
+    SubStep P;
+    SurfEB eb;
+    SurfSolve sv;
+    sf_sub_pre<NN>(o, cv, vl, s3, fc, dmy, C, w, L, P, eb, sv);
+    PROF_T0(t_sf);
+    while (sv.stage != SurfSolve::DONE) {
+      const double fx = eb.eval(o, s3, sv.x, 0., 0.);
+      surf_solve_consume(o, sv, eb, fx);
+    }
+    PROF_ADD(3, t_sf);
+    sf_sub_post<NN>(o, cv, vl, s3, fc, dmy, C, w, L, P, eb, sv, nullptr, nullptr, 0u);
+  } while (L.hidx < L.endhidx);
+  return sf_end<NN>(o, cv, s3, C, w, L);
 }
 
 }  // namespace vic

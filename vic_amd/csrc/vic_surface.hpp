@@ -44,205 +44,86 @@ struct SoilThermalEqn {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Finite-difference soil temperature profile (solve_T_profile + calc_soil_thermal_fluxes, frozen_soil.c:105-225,
-// 305-505), laid out for a 64-lane wavefront.
-//
-// Node columns live in LDS as [node][lane] (ds_read/ds_write_b64 with a per-lane node index are bank-conflict
-// free: the two 32-lane halves never collide), so every lane can be at ITS OWN node: the reference's loop nest
-//      sweeps (<=1000) { nodes j { closed-form update | Brent (<=1000 residual evaluations with a pow) } }
-// is flattened into ONE wave loop in which each lane carries its own (sweep, node, Brent) state and advances by one
-// unit of work per trip.  A lane whose node is unfrozen moves to the next node while its neighbours iterate their
-// Brent; a lane that has converged waits only for the slowest lane's TOTAL work instead of for the slowest lane at
-// every node of every sweep.  Per lane the sequence of operations, and therefore the result, is the reference's.
-//
-// A-D of the explicit scheme (frozen_soil.c:161-213) depend only on kappa, Cs, the node geometry and dt, i.e. they are
-// the same for every residual evaluation of one Brent solve on Tsurf (upstream keeps them in static arrays for that
-// reason; SURVEY.md Finding 1.1), so they are built once per calc_surf_energy_bal call.  EI = E*(0-ice) serves the
-// closed-form update; E, ice, moist and the freezing-curve parameters of a frozen node are fetched when its Brent
-// starts (in compat mode the LAYER arrays max_moist(mm)/bubble/expt followed by the node arrays: Finding 1.2).
+// Finite-difference soil temperature profile: what the ground-surface balance hands to the profile-solve kernel
+// (vic_profile.hpp).  One record per node, PREC doubles, records of one HRU contiguous ("item block"):
+//   [0] T0 (previous-step temperature; node 0: replaced by the trial surface temperature at solve time)
+//   [1] A  [2] B  [3] C  [4] D     explicit-scheme coefficients (frozen_soil.c:161-213); node 0 [1]: frozen_on flag
+//   [5] E*(0-ice)                  latent term of the closed-form (unfrozen) update
+//   [6] E  [7] moist  [8] ice      inputs of the frozen-node residual (soil_thermal_eqn.c)
+//   [9] max_moist [10] bubble [11] expt   freezing-curve parameters the reference would read for this node: the node
+//                                  arrays ("fixed"), or the LAYER arrays indexed by node as shipped ("compat",
+//                                  frozen_soil.c:218-221: max_moist in mm for j < 3, then the node arrays shifted by 3)
+// A-D depend only on kappa, Cs, the node geometry and dt, i.e. they are the same for every residual evaluation of one
+// Brent solve on Tsurf (upstream keeps them in static arrays for that reason; SURVEY.md Finding 1.1).
 // ------------------------------------------------------------------------------------------------
-constexpr int PROF_NARR = 7;   // T, T0, A, B, C, D, EI
+constexpr int PREC = 12;
+enum { PR_T0 = 0, PR_A, PR_B, PR_C, PR_D, PR_EI, PR_E, PR_MOIST, PR_ICE, PR_MAXM, PR_BUB, PR_EXPT };
 
 template <int NN>
-constexpr size_t prof_lds_bytes() { return NN > 3 ? (size_t)(PROF_NARR * 8 + 4) * NN * 64 : 0; }
-
-template <int NN>
-struct ProfLds {
-  double* base;   // [PROF_NARR][NN][64] doubles of this wave
-  int* fbc;       // [NN][64] fallback counters of the current solve
-  int lane;
-  VIC_DEV double& T(int j) const { return base[(0 * NN + j) * 64 + lane]; }
-  VIC_DEV double& T0(int j) const { return base[(1 * NN + j) * 64 + lane]; }
-  VIC_DEV double& A(int j) const { return base[(2 * NN + j) * 64 + lane]; }
-  VIC_DEV double& B(int j) const { return base[(3 * NN + j) * 64 + lane]; }
-  VIC_DEV double& C(int j) const { return base[(4 * NN + j) * 64 + lane]; }
-  VIC_DEV double& D(int j) const { return base[(5 * NN + j) * 64 + lane]; }
-  VIC_DEV double& EI(int j) const { return base[(6 * NN + j) * 64 + lane]; }
-  VIC_DEV int& cnt(int j) const { return fbc[j * 64 + lane]; }
-};
-
-template <int NN>
-VIC_DEV double profile_E(const Opt& o, const CellView& cv, int j, int Nn, double Dp) {
-  if (!o.EXP_TRANS) {
-    double al = cv.node(CPN_ALPHA, j - 1);
-    return ICE_DENSITY * LF * al * al;
-  }
-  const double Bexp = log(Dp + 1.) / (double)(Nn - 1);
-  double z1 = cv.node(CPN_ZSUM, j) + 1;
-  return 4 * Bexp * Bexp * ICE_DENSITY * LF * z1 * z1;
-}
-
-template <int NN>
-VIC_DEV void profile_coefficients(const Opt& o, const CellView& cv, const Nodes<NN>& nd, double deltat, double Dp, const ProfLds<NN>& S) {
+VIC_DEV void profile_item_store(const Opt& o, const CellView& cv, const Soil3& s3, const Nodes<NN>& nd, double deltat, bool frozen_on,
+                                double* __restrict__ blk) {
   const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
+  const double Dp = cv.s(CP_DP);
   const double Bexp = o.EXP_TRANS ? log(Dp + 1.) / (double)(Nn - 1) : 0.0;
 #pragma unroll
   for (int j = 0; j < NN; j++) {
-    if (j < Nn) S.T0(j) = nd.T[j];
-    if (j >= 1 && (j < Nn - 1 || (o.NOFLUX && j == Nn - 1))) {
-      const double kup = (j < Nn - 1) ? nd.kappa[(j + 1 < NN) ? j + 1 : j] : nd.kappa[j];
-      double E;
-      if (!o.EXP_TRANS) {
-        double al = cv.node(CPN_ALPHA, j - 1), be = cv.node(CPN_BETA, j - 1), ga = cv.node(CPN_GAMMA, j - 1);
-        S.A(j) = nd.Cs[j] * al * al;
-        S.B(j) = (kup - nd.kappa[j - 1]) * deltat;
-        S.C(j) = 2 * deltat * nd.kappa[j] * al / ga;
-        S.D(j) = 2 * deltat * nd.kappa[j] * al / be;
-        E = ICE_DENSITY * LF * al * al;
-      } else {
-        double z1 = cv.node(CPN_ZSUM, j) + 1;
-        S.A(j) = 4 * Bexp * Bexp * nd.Cs[j] * z1 * z1;
-        S.B(j) = (kup - nd.kappa[j - 1]) * deltat;
-        S.C(j) = 4 * deltat * nd.kappa[j];
-        S.D(j) = 2 * deltat * nd.kappa[j] * Bexp;
-        E = 4 * Bexp * Bexp * ICE_DENSITY * LF * z1 * z1;
-      }
-      S.EI(j) = E * (0. - nd.ice[j]);
+    if (j >= Nn) continue;
+    double* r = blk + j * PREC;
+    r[PR_T0] = nd.T[j];
+    if (j == 0) { r[PR_A] = frozen_on ? 1.0 : 0.0; continue; }
+    if (!(j < Nn - 1 || o.NOFLUX)) continue;
+    const double kup = (j < Nn - 1) ? nd.kappa[(j + 1 < NN) ? j + 1 : j] : nd.kappa[j];
+    double E;
+    if (!o.EXP_TRANS) {
+      const double al = cv.node(CPN_ALPHA, j - 1), be = cv.node(CPN_BETA, j - 1), ga = cv.node(CPN_GAMMA, j - 1);
+      r[PR_A] = nd.Cs[j] * al * al;
+      r[PR_B] = (kup - nd.kappa[j - 1]) * deltat;
+      r[PR_C] = 2 * deltat * nd.kappa[j] * al / ga;
+      r[PR_D] = 2 * deltat * nd.kappa[j] * al / be;
+      E = ICE_DENSITY * LF * al * al;
+    } else {
+      const double z1 = cv.node(CPN_ZSUM, j) + 1;
+      r[PR_A] = 4 * Bexp * Bexp * nd.Cs[j] * z1 * z1;
+      r[PR_B] = (kup - nd.kappa[j - 1]) * deltat;
+      r[PR_C] = 4 * deltat * nd.kappa[j];
+      r[PR_D] = 2 * deltat * nd.kappa[j] * Bexp;
+      E = 4 * Bexp * Bexp * ICE_DENSITY * LF * z1 * z1;
     }
+    r[PR_EI] = E * (0. - nd.ice[j]);
+    r[PR_E] = E; r[PR_MOIST] = nd.moist[j]; r[PR_ICE] = nd.ice[j];
+    if (o.frozen_compat) {
+      if (j < 3) { r[PR_MAXM] = s3.max_moist[j]; r[PR_BUB] = cv.lay(CPL_BUBBLE, j); r[PR_EXPT] = cv.lay(CPL_EXPT, j); }
+      else { r[PR_MAXM] = cv.node(CPN_MAX_MOIST, j - 3); r[PR_BUB] = cv.node(CPN_BUBBLE, j - 3); r[PR_EXPT] = cv.node(CPN_EXPT, j - 3); }
+    } else { r[PR_MAXM] = cv.node(CPN_MAX_MOIST, j); r[PR_BUB] = cv.node(CPN_BUBBLE, j); r[PR_EXPT] = cv.node(CPN_EXPT, j); }
   }
 }
 
-// One profile solve; S.T0(0) holds the trial surface temperature.  Results: S.T(j), S.cnt(j), fbmask.
-template <int NN>
-VIC_DEV bool solve_T_profile(const Opt& o, bool frozen_on, const CellView& cv, const Soil3& s3, const Nodes<NN>& nd,
-                             const ProfLds<NN>& S, unsigned& fbmask) {
-  const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
-  const int MAXIT = 1000;
-  const double threshold = 1.e-2;
-  const double Dp = cv.s(CP_DP);
-#pragma unroll
-  for (int j = 0; j < NN; j++)
-    if (j < Nn) { S.T(j) = S.T0(j); S.cnt(j) = 0; }
-  fbmask = 0;
-  const int jlast = o.NOFLUX ? Nn : Nn - 1;     // exclusive upper node of a sweep
-  bool ok = true, converged = false;
-  bool done = (jlast <= 1);
-  if (done) converged = true;
-  int it = 1, j = 1;
-  double maxdiff = threshold, oldT = 0;
-  bool in_brent = false;
-  Brent br;
-  SoilThermalEqn eq;
-  br.phase = Brent::DONE;
-  while (!done) {
-    PROF_WAVE(4); PROF_LANE(5);
-    bool node_done = false;
-    double newT = 0;
-    if (!in_brent) {
-      oldT = S.T(j);
-      const bool bottom = (j == Nn - 1);        // only reached with NOFLUX (frozen_soil.c:423-464)
-      const double Tdn = bottom ? oldT : S.T(j + 1), Tup = S.T(j - 1);
-      if (oldT >= 0 || !frozen_on) {
-        const double A = S.A(j), B = S.B(j), C = S.C(j), D = S.D(j);
-        if (!o.EXP_TRANS) newT = (A * S.T0(j) + B * (Tdn - Tup) + C * Tdn + D * Tup + S.EI(j)) / (A + C + D);
-        else newT = (A * S.T0(j) + B * (Tdn - Tup) + C * (Tdn + Tup) - D * (Tdn - Tup) + S.EI(j)) / (A + 2. * C);
-        node_done = true;
-      } else {
-        eq.TL = Tdn; eq.TU = Tup; eq.T0 = S.T0(j); eq.moist = nd.moist[j]; eq.ice0 = nd.ice[j];
-        eq.A = S.A(j); eq.B = S.B(j); eq.C = S.C(j); eq.D = S.D(j); eq.E = profile_E<NN>(o, cv, j, Nn, Dp);
-        eq.EXP_TRANS = o.EXP_TRANS; eq.node = j;
-        if (o.frozen_compat) {
-          if (j < 3) { eq.max_moist = s3.max_moist[j]; eq.bubble = cv.lay(CPL_BUBBLE, j); eq.expt = cv.lay(CPL_EXPT, j); }
-          else { eq.max_moist = cv.node(CPN_MAX_MOIST, j - 3); eq.bubble = cv.node(CPN_BUBBLE, j - 3); eq.expt = cv.node(CPN_EXPT, j - 3); }
-        } else { eq.max_moist = cv.node(CPN_MAX_MOIST, j); eq.bubble = cv.node(CPN_BUBBLE, j); eq.expt = cv.node(CPN_EXPT, j); }
-        br.start(eq.T0 - SOIL_DT, eq.T0 + SOIL_DT);
-        in_brent = true;
-      }
-    }
-    if (in_brent) {
-      PROF_LANE(6);
-      const double fx = eq(br.x);
-      br.advance(fx);
-      if (br.phase == Brent::DONE) {
-        double r = br.result;
-        if (is_error(r)) {
-          if (o.TFALLBACK) { r = eq.T0; fbmask |= (1u << j); S.cnt(j) += 1; }
-          else { ok = false; done = true; }
-        }
-        newT = r;
-        in_brent = false;
-        node_done = true;
-      }
-    }
-    if (node_done) {
-      S.T(j) = newT;
-      const double diff = fabs(oldT - newT);
-      if (diff > maxdiff) maxdiff = diff;
-      j++;
-      if (j >= jlast) {                           // end of a Gauss-Seidel sweep (frozen_soil.c:466)
-        if (maxdiff <= threshold) { converged = true; done = true; }
-        else if (it >= MAXIT) done = true;
-        else { it++; j = 1; maxdiff = threshold; }
-      }
-    }
-  }
-  if (!ok) return false;
-  if (o.TFALLBACK) {            // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T[j]); Tlast == T0
-#pragma unroll 1
-    for (int k = 1; k < Nn - 1; k++) {
-      const double Tk = S.T(k), Tm = S.T(k - 1), Tp = S.T(k + 1), Lk = S.T0(k), Lm = S.T0(k - 1), Lp = S.T0(k + 1);
-      if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
-        S.T(k) = 0.5 * (Tm + Tp);
-        fbmask |= (1u << k);
-        S.cnt(k) += 1;
-      }
-    }
-  }
-  if (!converged) {
-    if (o.TFALLBACK) {
-#pragma unroll 1
-      for (int k = 0; k < Nn; k++) { S.T(k) = S.T0(k); S.cnt(k) += 1; }
-      fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
-    } else return false;
-  }
-  return true;
-}
-
-// Residual of the ground-surface energy balance (func_surf_energy_bal.c:9-403)
-template <int NN>
-struct SurfEB {
-  // constant inputs
-  const Opt* o; const CellView* cv; const Soil3* s3; const Nodes<NN>* nd;
-  ProfLds<NN> S;
+// Residual of the ground-surface energy balance (func_surf_energy_bal.c:9-403).  Plain data, so that the evaluation
+// kernel can park it in HBM between the rounds of the Brent iteration on Tsurf: Const is written once per sub-step,
+// Mut ("last evaluation wins", the reference passes these by pointer) after every evaluation.
+struct SurfEBConst {
   VegMonth vm;
-  bool VEG, frozen_on, INCLUDE_SNOW, SNOWING, overstory;
+  int VEG, frozen_on, INCLUDE_SNOW, SNOWING, overstory, pad_;
   double delta_t, Cs1, Cs2, D1, D2, T1_old, T2, Ts_old, bubble, dp, expt, ice0, kappa1, kappa2, max_moist, moist, elevation,
          b_infilt, resid0;
   double NetShortBare, NetShortGrnd, NetShortSnow, Tair, atmos_density, atmos_pressure, LongBareIn, LongSnowIn, surf_atten, vp, vpd;
   double Wdew, rainfall, Le, Advection, OldTSurf, kappa_snow, melt_energy, snow_coverage, snow_density, snow_swq, snow_water;
   double U_under, zref_under, disp_under, z0_under, ra_under;
-  const double* lmoist; const double* lice; const double* root;
-  // state mutated by evaluations ("last evaluation wins")
+  double lmoist[3], lice[3], root[3];
+};
+struct SurfEBMut {
   double Tsnow_surf;
   double Tnew2;                   // Tnew_node[2] of the last evaluation
-  unsigned fbmask;                // T_fbflag bits of the last profile solve
   double ra_used[2];
-  VegVar* vv;
-  double* layerevap;              // [3]
+  VegVar vv;
+  double layerevap[3];
   double deltaCC, refreeze_energy, vapor_flux, blowing_flux, surface_flux;
   double NetLongBare, NetLongSnow, T1, deltaH, fusion, grnd_flux, latent_heat, latent_heat_sub, sensible_heat, snow_flux, error;
+};
 
-  VIC_DEV double operator()(double Ts) {
+struct SurfEB : SurfEBConst, SurfEBMut {
+  // T1_fd / T2_fd: nodes 1 and 2 of the finite-difference profile solved for this Ts (ignored with QUICK_FLUX)
+  VIC_DEV double eval(const Opt& o, const Soil3& s3, double Ts, double T1_fd, double T2_fd) {
     PROF_WAVE(7); PROF_LANE(8);
     const double TMean = Ts;
     const double Tmp = TMean + KELVIN;
@@ -250,23 +131,17 @@ struct SurfEB {
     else if (INCLUDE_SNOW) { snow_flux = 0; Tsnow_surf = TMean; }
     else snow_flux = 0;
     const double att = (snow_coverage + (1. - snow_coverage) * surf_atten);
-    if (o->QUICK_FLUX) {
+    if (o.QUICK_FLUX) {
       T1 = estimate_T1(TMean, T1_old, T2, D1, D2, kappa1, kappa2, Cs2, dp, delta_t);
-      if (o->GRND_FLUX_TYPE == VIC_GF_406) grnd_flux = att * (kappa1 / D1 * ((T1) - TMean));
+      if (o.GRND_FLUX_TYPE == VIC_GF_406) grnd_flux = att * (kappa1 / D1 * ((T1) - TMean));
       else grnd_flux = att * (kappa1 / D1 * ((T1) - TMean) + (kappa2 / D2 * (1. - exp(-D1 / dp)) * (T2 - (T1)))) / 2.;
     } else {
-      if constexpr (NN > 3) {
-        PROF_T0(t_prof);
-        S.T0(0) = TMean;                                        // T_node[0] = TMean (func_surf_energy_bal.c:190)
-        if (!solve_T_profile<NN>(*o, frozen_on, *cv, *s3, *nd, S, fbmask)) return ERROR_VAL;
-        PROF_ADD(4, t_prof);
-        T1 = S.T(1);
-        Tnew2 = S.T(2);
-      }
-      if (o->GRND_FLUX_TYPE == VIC_GF_406) grnd_flux = att * (kappa1 / D1 * ((T1) - TMean));
+      T1 = T1_fd;                                              // solve_T_profile with T_node[0] = TMean (func_surf_energy_bal.c:190)
+      Tnew2 = T2_fd;
+      if (o.GRND_FLUX_TYPE == VIC_GF_406) grnd_flux = att * (kappa1 / D1 * ((T1) - TMean));
       else grnd_flux = att * (kappa1 / D1 * ((T1) - TMean) + (kappa2 / D2 * (Tnew2 - (T1)))) / 2.;
     }
-    if (o->GRND_FLUX_TYPE == VIC_GF_FULL) deltaH = att * (Cs1 * ((Ts_old + T1_old) - (TMean + T1)) * D1 / delta_t / 2.);
+    if (o.GRND_FLUX_TYPE == VIC_GF_FULL) deltaH = att * (Cs1 * ((Ts_old + T1_old) - (TMean + T1)) * D1 / delta_t / 2.);
     else deltaH = (Cs1 * ((Ts_old + T1_old) - (TMean + T1)) * D1 / delta_t / 2.);
     if (frozen_on) {
       double ice;
@@ -274,7 +149,7 @@ struct SurfEB {
         ice = moist - maximum_unfrozen_water((TMean + T1) / 2., max_moist, bubble, expt);
         if (ice < 0.) ice = 0.;
       } else ice = 0.;
-      if (o->GRND_FLUX_TYPE == VIC_GF_FULL) fusion = att * (-ICE_DENSITY * LF * (ice0 - ice) * D1 / delta_t);
+      if (o.GRND_FLUX_TYPE == VIC_GF_FULL) fusion = att * (-ICE_DENSITY * LF * (ice0 - ice) * D1 / delta_t);
       else fusion = (-ICE_DENSITY * LF * (ice0 - ice) * D1 / delta_t);
     }
     if (INCLUDE_SNOW) {
@@ -295,11 +170,11 @@ struct SurfEB {
 
     double Evap;
     if (VEG && !SNOWING && vm.LAI > 0) {
-      Evap = canopy_evap(vm, *s3, lmoist, lice, *vv, true, Wdew, delta_t, NetBareRad, vpd, NetShortBare, Tair, ra_used[1], elevation,
+      Evap = canopy_evap(vm, s3, lmoist, lice, vv, true, Wdew, delta_t, NetBareRad, vpd, NetShortBare, Tair, ra_used[1], elevation,
                          rainfall, root, layerevap);
     } else if (!SNOWING) {
       double e0 = layerevap[0];
-      Evap = arno_evap(lmoist[0], lice[0], NetBareRad, Tair, vpd, s3->depth[0], max_moist * s3->depth[0] * 1000., elevation, b_infilt,
+      Evap = arno_evap(lmoist[0], lice[0], NetBareRad, Tair, vpd, s3.depth[0], max_moist * s3.depth[0] * 1000., elevation, b_infilt,
                        ra_used[0], delta_t, resid0, e0);
       layerevap[0] = e0;
     } else Evap = 0.;
@@ -338,28 +213,73 @@ struct SurfEB {
   }
 };
 
-struct SurfOut { double Tsurf, melt, ppt; bool ok; };
+// What calc_surf_energy_bal keeps from its set-up for the bookkeeping after the solve
+struct SurfPost {
+  double NetLongSnow, NetShortGrnd, NetShortSnow, SnowAlbedo, SnowLatent, SnowLatentSub, SnowSensible, delta_coverage, snow_coverage,
+         BareAlbedo, LongUnderIn, melt_energy, rainfall, NetShortBare, TmpNetShortSnow, melt_in, ppt_in, delta_t;
+  int INCLUDE_SNOW, is_artificial_bare;
+};
 
-// calc_surf_energy_bal (calc_surf_energy_bal.c:7-692).  lmoist/lice/lT/layerevap are the three soil layers of the
-// current sub-step (moist in, ice/T/evap out).  melt/ppt are in/out.
+// The Brent iteration on Tsurf (calc_surf_energy_bal.c:430-487) and the final evaluation at the root (:489-506), one
+// residual evaluation per call of surf_solve_consume: the same code runs inside a lane's loop (QUICK_FLUX) and across
+// launches of the evaluation kernel (finite-difference profile).
+struct SurfSolve {
+  enum { ROOT = 0, FINAL = 1, DONE = 2 };
+  Brent br;
+  double x, Tsurf, snow_surf_temp, Ts_old, error;
+  int stage, fbflag, fbcount, ok;
+};
+
+VIC_DEV void surf_solve_begin(const Opt& o, SurfSolve& sv, double T0, double Tair, bool INCLUDE_SNOW, double snow_surf_temp) {
+  sv.Ts_old = T0; sv.snow_surf_temp = snow_surf_temp; sv.fbflag = 0; sv.fbcount = 0; sv.ok = 1; sv.error = 0; sv.Tsurf = 0;
+  if (o.FULL_ENERGY) {
+    double T_lower, T_upper;
+    if (INCLUDE_SNOW) { T_lower = T0 - SURF_DT; T_upper = 0.; }
+    else { T_lower = 0.5 * (T0 + Tair) - SURF_DT; T_upper = 0.5 * (T0 + Tair) + SURF_DT; }
+    sv.br.start(T_lower, T_upper);
+    sv.stage = SurfSolve::ROOT; sv.x = sv.br.x;
+  } else {
+    sv.br.start(0, 0);
+    sv.Tsurf = Tair; sv.x = Tair; sv.stage = SurfSolve::FINAL;
+  }
+}
+
+VIC_DEV void surf_solve_consume(const Opt& o, SurfSolve& sv, SurfEBMut& m, double fx) {
+  if (sv.stage == SurfSolve::ROOT) {
+    sv.br.advance(fx);
+    if (sv.br.phase == Brent::DONE) {
+      double Tsurf = sv.br.result;
+      if (is_error(Tsurf)) {
+        if (o.TFALLBACK) { Tsurf = sv.Ts_old; sv.fbflag = 1; sv.fbcount++; }
+        else sv.ok = 0;
+      }
+      sv.Tsurf = Tsurf; sv.x = Tsurf; sv.stage = SurfSolve::FINAL;
+      m.Tsnow_surf = sv.snow_surf_temp;        // the final evaluation starts from the stored pack temperature
+    } else sv.x = sv.br.x;
+  } else {
+    sv.error = fx;
+    if (fx == ERROR_VAL) sv.ok = 0;
+    sv.stage = SurfSolve::DONE;
+  }
+}
+
+// calc_surf_energy_bal.c:7-428: everything before the root finder.  lmoist/lice/layerevap are the three soil layers of
+// the current sub-step.
 template <int NN>
-VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, int hidx,
-                                     int veg_idx, int month, bool is_artificial_bare, bool overstory, double Le, double LongUnderIn,
-                                     double NetLongSnow, double NetShortGrnd, double NetShortSnow, double OldTSurf, double ShortUnderIn,
-                                     double SnowAlbedo, double SnowLatent, double SnowLatentSub, double SnowSensible, double Tair,
-                                     double VPDcanopy, double VPcanopy, double delta_coverage, double ice0, double melt_energy,
-                                     double moist0, double snow_coverage, double snow_depth_avg, double BareAlbedo, double surf_atten,
-                                     const Vc& Ra, const Vc& U, const Vc& disp, const Vc& zref, const Vc& z0, double* ra_used,
-                                     double melt_in, double ppt_in, double rainfall, const double* root, int INCLUDE_SNOW, int UnderStory,
-                                     int dt, const double* lmoist, double* lice, double* lT, double* layerevap, Nodes<NN>& nd,
-                                     SoilEnergy& e, Snow& snow, VegVar& vv) {
+VIC_DEV void surf_setup(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, int hidx, int veg_idx,
+                        int month, bool is_artificial_bare, bool overstory, double Le, double LongUnderIn, double NetLongSnow,
+                        double NetShortGrnd, double NetShortSnow, double OldTSurf, double ShortUnderIn, double SnowAlbedo,
+                        double SnowLatent, double SnowLatentSub, double SnowSensible, double Tair, double VPDcanopy, double VPcanopy,
+                        double delta_coverage, double ice0, double melt_energy, double moist0, double snow_coverage,
+                        double snow_depth_avg, double BareAlbedo, double surf_atten, const Vc& Ra, const Vc& U, const Vc& disp,
+                        const Vc& zref, const Vc& z0, const double* ra_used, double melt_in, double ppt_in, double rainfall,
+                        const double* root, int INCLUDE_SNOW, int UnderStory, int dt, const double* lmoist, const double* lice,
+                        const double* layerevap, const Nodes<NN>& nd, const SoilEnergy& e, const Snow& snow, const VegVar& vv,
+                        SurfEB& eb, SurfPost& P, SurfSolve& sv) {
   const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
-  SurfOut out;
-  out.ok = true; out.melt = melt_in; out.ppt = ppt_in;
   const VegMonth vm = veg_month(vl, veg_idx, month);
   const bool frozen_on = (cv.s(CP_FS_ACTIVE) != 0.0) && o.FROZEN_SOIL;
   const double delta_t = (double)dt * 3600.;
-  const double Ts_old = nd.T[0];
   const double kappa_snow = (snow.depth > 0.) ? K_SNOW * (snow.density) * (snow.density) / snow_depth_avg : 0;
   const double NetShortBare = (ShortUnderIn * (1. - (snow_coverage + delta_coverage)) * (1. - BareAlbedo)
                                + ShortUnderIn * (delta_coverage) * (1. - SnowAlbedo));
@@ -368,19 +288,18 @@ VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const Veg
   if (INCLUDE_SNOW || snow.swq == 0) { TmpNetLongSnow = NetLongSnow; TmpNetShortSnow = NetShortSnow; LongSnowIn = snow_coverage * LongUnderIn; }
   else { TmpNetShortSnow = 0.; TmpNetLongSnow = 0.; LongSnowIn = 0.; }
 
-  SurfEB<NN> eb;
-  if constexpr (NN > 3) {
-    // one LDS slab per wave (block = one wave): node columns of the profile solver
-    extern __shared__ double vic_dyn_lds[];       // prof_lds_bytes<NN>() bytes, sized by the launch
-    eb.S.base = vic_dyn_lds; eb.S.fbc = reinterpret_cast<int*>(vic_dyn_lds + PROF_NARR * NN * 64); eb.S.lane = threadIdx.x & 63;
-    if (!o.QUICK_FLUX) profile_coefficients<NN>(o, cv, nd, delta_t, cv.s(CP_DP), eb.S);
-  } else { eb.S.base = nullptr; eb.S.fbc = nullptr; eb.S.lane = 0; }
-  eb.o = &o; eb.cv = &cv; eb.s3 = &s3; eb.nd = &nd; eb.vm = vm;
+  P.NetLongSnow = NetLongSnow; P.NetShortGrnd = NetShortGrnd; P.NetShortSnow = NetShortSnow; P.SnowAlbedo = SnowAlbedo;
+  P.SnowLatent = SnowLatent; P.SnowLatentSub = SnowLatentSub; P.SnowSensible = SnowSensible; P.delta_coverage = delta_coverage;
+  P.snow_coverage = snow_coverage; P.BareAlbedo = BareAlbedo; P.LongUnderIn = LongUnderIn; P.melt_energy = melt_energy;
+  P.rainfall = rainfall; P.NetShortBare = NetShortBare; P.TmpNetShortSnow = TmpNetShortSnow; P.melt_in = melt_in; P.ppt_in = ppt_in;
+  P.delta_t = delta_t; P.INCLUDE_SNOW = INCLUDE_SNOW; P.is_artificial_bare = is_artificial_bare;
+
+  eb.vm = vm;
   eb.VEG = (!is_artificial_bare) && (vm.LAI > 0.0);
-  eb.frozen_on = frozen_on; eb.INCLUDE_SNOW = INCLUDE_SNOW != 0; eb.SNOWING = snow.snow != 0; eb.overstory = overstory;
+  eb.frozen_on = frozen_on; eb.INCLUDE_SNOW = INCLUDE_SNOW != 0; eb.SNOWING = snow.snow != 0; eb.overstory = overstory; eb.pad_ = 0;
   eb.delta_t = delta_t; eb.Cs1 = e.Cs[0]; eb.Cs2 = e.Cs[1];
   eb.D1 = cv.node(CPN_ZSUM, 1) - cv.node(CPN_ZSUM, 0); eb.D2 = cv.node(CPN_ZSUM, 2) - cv.node(CPN_ZSUM, 1);
-  eb.T1_old = nd.T[1]; eb.T2 = nd.T[Nn - 1 < NN ? Nn - 1 : NN - 1]; eb.Ts_old = Ts_old;
+  eb.T1_old = nd.T[1]; eb.T2 = nd.T[Nn - 1 < NN ? Nn - 1 : NN - 1]; eb.Ts_old = nd.T[0];
   eb.bubble = cv.lay(CPL_BUBBLE, 0); eb.dp = cv.s(CP_DP); eb.expt = cv.lay(CPL_EXPT, 0); eb.ice0 = ice0;
   eb.kappa1 = e.kappa[0]; eb.kappa2 = e.kappa[1];
   eb.max_moist = s3.max_moist[0] / (s3.depth[0] * 1000.); eb.moist = moist0;
@@ -393,52 +312,56 @@ VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const Veg
   eb.snow_swq = snow.swq; eb.snow_water = snow.surf_water;
   eb.U_under = U.v[UnderStory]; eb.zref_under = zref.v[UnderStory]; eb.disp_under = disp.v[UnderStory];
   eb.z0_under = z0.v[UnderStory]; eb.ra_under = Ra.v[UnderStory];
-  eb.lmoist = lmoist; eb.lice = lice; eb.root = root;
+#pragma unroll
+  for (int l = 0; l < 3; l++) { eb.lmoist[l] = lmoist[l]; eb.lice[l] = lice[l]; eb.root[l] = root[l]; eb.layerevap[l] = layerevap[l]; }
   eb.Tsnow_surf = snow.surf_temp;
-  eb.Tnew2 = 0; eb.fbmask = 0;
+  eb.Tnew2 = 0;
   eb.ra_used[0] = ra_used[0]; eb.ra_used[1] = ra_used[1];
-  eb.vv = &vv; eb.layerevap = layerevap;
+  eb.vv = vv;
   eb.deltaCC = e.deltaCC; eb.refreeze_energy = e.refreeze_energy; eb.vapor_flux = snow.vapor_flux;
   eb.blowing_flux = snow.blowing_flux; eb.surface_flux = snow.surface_flux;
   eb.NetLongBare = 0; eb.NetLongSnow = TmpNetLongSnow; eb.T1 = 0; eb.deltaH = e.deltaH; eb.fusion = e.fusion;
   eb.grnd_flux = e.grnd_flux; eb.latent_heat = e.latent; eb.latent_heat_sub = e.latent_sub; eb.sensible_heat = e.sensible;
   eb.snow_flux = e.snow_flux; eb.error = e.error;
 
-  double Tsurf;
-  int Tsurf_fbflag = 0, Tsurf_fbcount = 0;
-  if (o.FULL_ENERGY) {
-    double T_lower, T_upper;
-    if (INCLUDE_SNOW) { T_lower = nd.T[0] - SURF_DT; T_upper = 0.; }
-    else { T_lower = 0.5 * (nd.T[0] + Tair) - SURF_DT; T_upper = 0.5 * (nd.T[0] + Tair) + SURF_DT; }
-    Tsurf = root_brent(T_lower, T_upper, eb);
-    if (is_error(Tsurf)) {
-      if (o.TFALLBACK) { Tsurf = Ts_old; Tsurf_fbflag = 1; Tsurf_fbcount++; }
-      else out.ok = false;
-    }
-  } else Tsurf = Tair;
+  surf_solve_begin(o, sv, nd.T[0], Tair, INCLUDE_SNOW != 0, snow.surf_temp);
+}
 
-  eb.Tsnow_surf = snow.surf_temp;        // the final evaluation runs on a fresh object (calc_surf_energy_bal.c:489-506)
-  double error = eb(Tsurf);
-  if (error == ERROR_VAL) out.ok = false;
-  e.error = error;
+struct SurfOut { double Tsurf, melt, ppt; bool ok; };
+
+// calc_surf_energy_bal.c:489-692: bookkeeping after the final evaluation.  Tnew/cntnew/fbmask: the finite-difference
+// profile of the final evaluation (unused with QUICK_FLUX).  lice/lT: layer ice and temperature out.
+template <int NN>
+VIC_DEV SurfOut surf_post(const Opt& o, const CellView& cv, const Soil3& s3, const SurfPost& P, const SurfEB& eb, const SurfSolve& sv,
+                          const double* Tprof, const int* cntprof, unsigned fbmask, const double* lmoist, double* lice, double* lT,
+                          double* layerevap, double* ra_used, Nodes<NN>& nd, SoilEnergy& e, Snow& snow, VegVar& vv) {
+  const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
+  SurfOut out;
+  out.ok = sv.ok != 0; out.melt = P.melt_in; out.ppt = P.ppt_in;
+  const double Tsurf = sv.Tsurf;
+  const bool frozen_on = eb.frozen_on != 0;
+  const bool INCLUDE_SNOW = P.INCLUDE_SNOW != 0;
+  const double delta_t = P.delta_t;
+  e.error = sv.error;
   e.deltaCC = eb.deltaCC; e.refreeze_energy = eb.refreeze_energy; e.deltaH = eb.deltaH; e.fusion = eb.fusion;
   e.grnd_flux = eb.grnd_flux; e.latent = eb.latent_heat; e.latent_sub = eb.latent_heat_sub; e.sensible = eb.sensible_heat;
   e.snow_flux = eb.snow_flux;
   snow.vapor_flux = eb.vapor_flux; snow.blowing_flux = eb.blowing_flux; snow.surface_flux = eb.surface_flux;
   ra_used[0] = eb.ra_used[0]; ra_used[1] = eb.ra_used[1];
-  TmpNetLongSnow = eb.NetLongSnow;
+  vv = eb.vv;
+#pragma unroll
+  for (int l = 0; l < 3; l++) layerevap[l] = eb.layerevap[l];
+  const double TmpNetLongSnow = eb.NetLongSnow;
   const double NetLongBare = eb.NetLongBare;
 
   double Tnew[NN];
   int cntnew[NN];
 #pragma unroll
   for (int n = 0; n < NN; n++) { Tnew[n] = 0; cntnew[n] = 0; }
-  if constexpr (NN > 3) {
-    if (!o.QUICK_FLUX) {
+  if (!o.QUICK_FLUX) {
 #pragma unroll
-      for (int n = 0; n < NN; n++)
-        if (n < Nn) { Tnew[n] = eb.S.T(n); cntnew[n] = eb.S.cnt(n); }
-    }
+    for (int n = 0; n < NN; n++)
+      if (n < Nn) { Tnew[n] = Tprof[n]; cntnew[n] = cntprof[n]; }
   }
   if (o.QUICK_FLUX || !(o.FULL_ENERGY || frozen_on)) {
     Tnew[0] = Tsurf;
@@ -455,25 +378,25 @@ VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const Veg
   else if (!estimate_layer_ice_content<NN>(o, cv, s3, nd.T, lmoist, lice, lT)) out.ok = false;
 
   if (!snow.snow && !INCLUDE_SNOW) {                                     // calc_surf_energy_bal.c:527-546
-    if (!is_artificial_bare) {
-      if (vm.LAI <= 0.0) { vv.throughfall = rainfall; out.ppt = vv.throughfall; }
+    if (!P.is_artificial_bare) {
+      if (eb.vm.LAI <= 0.0) { vv.throughfall = P.rainfall; out.ppt = vv.throughfall; }
       else out.ppt = vv.throughfall;
-    } else out.ppt = rainfall;
+    } else out.ppt = P.rainfall;
   }
-  e.NetShortGrnd = NetShortGrnd;
+  e.NetShortGrnd = P.NetShortGrnd;
   if (INCLUDE_SNOW) {
     e.NetLongUnder = NetLongBare + TmpNetLongSnow;
-    e.NetShortUnder = NetShortBare + TmpNetShortSnow + NetShortGrnd;
+    e.NetShortUnder = P.NetShortBare + P.TmpNetShortSnow + P.NetShortGrnd;
   } else {
-    e.NetLongUnder = NetLongBare + NetLongSnow;
-    e.NetShortUnder = NetShortBare + NetShortSnow + NetShortGrnd;
-    e.latent = (SnowLatent + e.latent);
-    e.latent_sub = (SnowLatentSub + e.latent_sub);
-    e.sensible = (SnowSensible + e.sensible);
+    e.NetLongUnder = NetLongBare + P.NetLongSnow;
+    e.NetShortUnder = P.NetShortBare + P.NetShortSnow + P.NetShortGrnd;
+    e.latent = (P.SnowLatent + e.latent);
+    e.latent_sub = (P.SnowLatentSub + e.latent_sub);
+    e.sensible = (P.SnowSensible + e.sensible);
   }
-  e.LongUnderOut = LongUnderIn - e.NetLongUnder;
-  e.AlbedoUnder = ((1. - (snow_coverage + delta_coverage)) * BareAlbedo + (snow_coverage + delta_coverage) * SnowAlbedo);
-  e.melt_energy = melt_energy;
+  e.LongUnderOut = P.LongUnderIn - e.NetLongUnder;
+  e.AlbedoUnder = ((1. - (P.snow_coverage + P.delta_coverage)) * P.BareAlbedo + (P.snow_coverage + P.delta_coverage) * P.SnowAlbedo);
+  e.melt_energy = P.melt_energy;
   e.Tsurf = (snow.coverage * snow.surf_temp + (1. - snow.coverage) * Tsurf);
 
   if (INCLUDE_SNOW) {                                                    // thin snowpack, calc_surf_energy_bal.c:589-679
@@ -511,10 +434,10 @@ VIC_DEV SurfOut calc_surf_energy_bal(const Opt& o, const CellView& cv, const Veg
     }
     snow.vapor_flux *= -1;
   }
-  e.Tsurf_fbflag = Tsurf_fbflag;
-  e.Tsurf_fbcount += Tsurf_fbcount;
+  e.Tsurf_fbflag = sv.fbflag;
+  e.Tsurf_fbcount += sv.fbcount;
 #pragma unroll
-  for (int n = 0; n < NN; n++) { nd.fbflag[n] = (eb.fbmask >> n) & 1u; nd.fbcount[n] += cntnew[n]; }
+  for (int n = 0; n < NN; n++) { nd.fbflag[n] = (fbmask >> n) & 1u; nd.fbcount[n] += cntnew[n]; }
   out.Tsurf = Tsurf;
   return out;
 }

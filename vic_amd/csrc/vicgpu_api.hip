@@ -4,6 +4,10 @@
 //   vic_hru_step<NN>   one lane per HRU: the per-HRU body of full_energy (full_energy.c:216-456) = aerodynamics,
 //                      prepare_full_energy, surface_fluxes (snow, ground energy balance, pot. evap), runoff.
 //                      HBM-side it is a streaming read-modify-write of the SoA state table; all physics is fp64 VALU.
+//   vic_fd_stage<NN>,  the same step for the finite-difference soil profile (FROZEN_SOIL / QUICK_FLUX off), cut at the
+//   vic_profile_solve<NN>, ground-surface root finder into a pipeline: stage kernel (everything around the root finder,
+//   vic_surf_eval      context parked in HBM) -> rounds of { profile solves on a compacted work list ; residual +
+//                      Brent step on Tsurf } -> stage kernel.  See vic_profile.hpp for why.
 //   vic_cell_reduce    one lane per cell: atmos->out_prec/out_rain/out_snow (full_energy.c:429-431) summed in hruList
 //                      order (deterministic, no atomics) and the Cv-weighted per-cell accumulators.
 #include <hip/hip_runtime.h>
@@ -13,7 +17,9 @@
 #include <string>
 #include <vector>
 #include "vicgpu.h"
+#include <type_traits>
 #include "vic_glacier.hpp"
+#include "vic_profile.hpp"
 
 using namespace vic;
 
@@ -41,7 +47,54 @@ struct KArgs {
   int* si;
   double* flux;
   int* hru_err;                     // [nhru]
+  // finite-difference pipeline only (null otherwise)
+  unsigned long long* ctx;          // parked per-HRU context, [word][nhru]
+  double* pin;                      // profile item blocks [nhru][Nn][PREC]
+  double* ts;                       // trial surface temperature [nhru]
+  const double* pout;               // profile solutions [nhru][pout_stride(Nn)]
+  int* hstate;                      // [nhru] 0 idle, 1 residual evaluation pending, 2 root found: stage kernel's turn
+  int* list;                        // work list the stage kernel appends to
+  int* count;
+  int phase;                        // 0: start of the step; p >= 1: after the root finder of sub-step p - 1
 };
+
+// ------------------------------------------------------------------------------------------------ parked context
+// Plain structs are parked word by word in a [word][nhru] table (coalesced for lanes = consecutive HRUs).
+template <class T>
+VIC_DEV void ctx_put(unsigned long long* __restrict__ base, size_t nh, size_t g, const T& v) {
+  static_assert(sizeof(T) % 8 == 0 && std::is_trivially_copyable<T>::value, "context structs are arrays of 8-byte words");
+  constexpr int NW = sizeof(T) / 8;
+  unsigned long long tmp[NW];
+  __builtin_memcpy(tmp, &v, sizeof(T));
+#pragma unroll
+  for (int i = 0; i < NW; i++) base[(size_t)i * nh + g] = tmp[i];
+}
+template <class T>
+VIC_DEV void ctx_get(const unsigned long long* __restrict__ base, size_t nh, size_t g, T& v) {
+  static_assert(sizeof(T) % 8 == 0 && std::is_trivially_copyable<T>::value, "context structs are arrays of 8-byte words");
+  constexpr int NW = sizeof(T) / 8;
+  unsigned long long tmp[NW];
+#pragma unroll
+  for (int i = 0; i < NW; i++) tmp[i] = base[(size_t)i * nh + g];
+  __builtin_memcpy(&v, tmp, sizeof(T));
+}
+constexpr size_t CW_SV = sizeof(SurfSolve) / 8, CW_EBM = sizeof(SurfEBMut) / 8, CW_EBC = sizeof(SurfEBConst) / 8,
+                 CW_P = sizeof(SubStep) / 8, CW_L = sizeof(SubLoop) / 8, CW_C = sizeof(StepConst) / 8;
+constexpr size_t CO_SV = 0, CO_EBM = CO_SV + CW_SV, CO_EBC = CO_EBM + CW_EBM, CO_P = CO_EBC + CW_EBC, CO_L = CO_P + CW_P,
+                 CO_C = CO_L + CW_L, CO_W = CO_C + CW_C;
+template <int NN> constexpr size_t ctx_words() { return CO_W + sizeof(HruWork<NN>) / 8; }
+
+// wave-aggregated append of this lane's HRU to a work list (order is irrelevant: HRUs never interact)
+VIC_DEV void list_append(int* __restrict__ list, int* count, bool pred, int g) {
+  const unsigned long long m = __ballot(pred);
+  if (m == 0) return;
+  const int lane = (int)__lane_id();
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, leader);
+  if (pred) list[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+}
 
 // ------------------------------------------------------------------------------------------------ state table I/O
 template <int NN>
@@ -190,78 +243,79 @@ VIC_DEV void store_flux(const KArgs& a, int g, const HruWork<NN>& w) {
 #undef FX
 }
 
-// ------------------------------------------------------------------------------------------------ HRU kernel
-template <int NN, bool GLAC>
-__global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
-  const int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= a.nhru) return;
-  const Opt& o = a.o;
+// ------------------------------------------------------------------------------------------------ HRU kernels
+struct HruId { int c, band, veg_idx; bool is_glacier, is_art_bare, run; };
+
+VIC_DEV HruId hru_id(const KArgs& a, int g) {
   const size_t nh = a.nhru;
-  const int c = a.hpi[(size_t)HPI_CELL * nh + g];
-  const int band = a.hpi[(size_t)HPI_BAND * nh + g];
-  const int veg_idx = a.hpi[(size_t)HPI_VEG_INDEX * nh + g];
-  const bool is_glacier = a.hpi[(size_t)HPI_IS_GLACIER * nh + g] != 0;
-  const bool is_art_bare = a.hpi[(size_t)HPI_IS_ARTIFICIAL_BARE * nh + g] != 0;
+  HruId id;
+  id.c = a.hpi[(size_t)HPI_CELL * nh + g];
+  id.band = a.hpi[(size_t)HPI_BAND * nh + g];
+  id.veg_idx = a.hpi[(size_t)HPI_VEG_INDEX * nh + g];
+  id.is_glacier = a.hpi[(size_t)HPI_IS_GLACIER * nh + g] != 0;
+  id.is_art_bare = a.hpi[(size_t)HPI_IS_ARTIFICIAL_BARE * nh + g] != 0;
   const double Cv = a.hpd[(size_t)HPD_CV * nh + g];
-  double root[3];
-#pragma unroll
-  for (int l = 0; l < 3; l++) root[l] = (double)(float)a.hpd[(size_t)(HPD_ROOT0 + l) * nh + g];
-  double* fx = a.flux;
-
-  int err = 0;
   // full_energy.c:220
-  const bool active = (Cv > 0.0) || (is_glacier && o.GLACIER_DYNAMICS && Cv >= 0.0);
-  CellView cv{a.cell_params, a.ncell, c, o.Nnode, o.Nband};
-  const double area = cv.band(CPB_AREAFRACT, band);
-  const bool run = active && ((area > 0) || (is_glacier && o.GLACIER_DYNAMICS && area >= 0.0));
-  // two instantiations share this body: GLAC = false handles ordinary HRUs (and writes the zero record of inactive
-  // ones), GLAC = true handles glacier HRUs; the domain numbering keeps either kind wave-uniform
-  if (is_glacier != GLAC && run) return;
-  if (!run) {
-    if (GLAC) return;
-    fx[(size_t)FX_OUT_PREC * nh + g] = 0; fx[(size_t)FX_OUT_RAIN * nh + g] = 0; fx[(size_t)FX_OUT_SNOW * nh + g] = 0;
-    fx[(size_t)FX_RUNOFF * nh + g] = 0; fx[(size_t)FX_BASEFLOW * nh + g] = 0;
-    fx[(size_t)FX_EVAP0 * nh + g] = 0; fx[(size_t)FX_EVAP1 * nh + g] = 0; fx[(size_t)FX_EVAP2 * nh + g] = 0;
-    fx[(size_t)FX_CANOPYEVAP * nh + g] = 0; fx[(size_t)FX_SNOW_VAPOR_FLUX * nh + g] = 0;
-    fx[(size_t)FX_SNOW_CANOPY_VAPOR_FLUX * nh + g] = 0; fx[(size_t)FX_GLAC_MASS_BALANCE * nh + g] = 0;
-    a.hru_err[g] = 0;
-    return;
-  }
-  VegLib vl{a.veglib};
-  Forcing fc{a.forcing, a.snowflag, a.ncell, c, o.NR + 1};
-  const Dmy dmy = a.dmy;
-  const int month = dmy.month;
+  const bool active = (Cv > 0.0) || (id.is_glacier && a.o.GLACIER_DYNAMICS && Cv >= 0.0);
+  const double area = a.cell_params[(size_t)VICGPU_CP_BAND(CPB_AREAFRACT, id.band, a.o.Nnode, a.o.Nband) * a.ncell + id.c];
+  id.run = active && ((area > 0) || (id.is_glacier && a.o.GLACIER_DYNAMICS && area >= 0.0));
+  return id;
+}
 
+VIC_DEV void store_zero_record(const KArgs& a, int g) {
+  const size_t nh = a.nhru;
+  double* fx = a.flux;
+  fx[(size_t)FX_OUT_PREC * nh + g] = 0; fx[(size_t)FX_OUT_RAIN * nh + g] = 0; fx[(size_t)FX_OUT_SNOW * nh + g] = 0;
+  fx[(size_t)FX_RUNOFF * nh + g] = 0; fx[(size_t)FX_BASEFLOW * nh + g] = 0;
+  fx[(size_t)FX_EVAP0 * nh + g] = 0; fx[(size_t)FX_EVAP1 * nh + g] = 0; fx[(size_t)FX_EVAP2 * nh + g] = 0;
+  fx[(size_t)FX_CANOPYEVAP * nh + g] = 0; fx[(size_t)FX_SNOW_VAPOR_FLUX * nh + g] = 0;
+  fx[(size_t)FX_SNOW_CANOPY_VAPOR_FLUX * nh + g] = 0; fx[(size_t)FX_GLAC_MASS_BALANCE * nh + g] = 0;
+  a.hru_err[g] = 0;
+}
+
+VIC_DEV Soil3 load_soil3(const CellView& cv) {
   Soil3 s3;
 #pragma unroll
   for (int l = 0; l < 3; l++) {
     s3.depth[l] = cv.lay(CPL_DEPTH, l); s3.max_moist[l] = cv.lay(CPL_MAX_MOIST, l); s3.Wcr[l] = cv.lay(CPL_WCR, l);
     s3.Wpwp[l] = cv.lay(CPL_WPWP, l); s3.resid_moist[l] = cv.lay(CPL_RESID_MOIST, l);
   }
+  return s3;
+}
 
-  PROF_T0(t_kernel);
-  HruWork<NN> w;
+// full_energy.c:216-354: state in, prepare_full_energy, aerodynamic resistances.  Returns the error bits.
+template <int NN, bool GLAC>
+VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView& cv, const VegLib& vl, const Forcing& fc, const Soil3& s3,
+                         HruWork<NN>& w, StepConst& C) {
+  const Opt& o = a.o;
+  const size_t nh = a.nhru;
+  const int month = a.dmy.month;
+  const int veg_idx = id.veg_idx;
+  int err = 0;
+  C.veg_idx = veg_idx; C.band = id.band; C.is_art_bare = id.is_art_bare ? 1 : 0;
+#pragma unroll
+  for (int l = 0; l < 3; l++) C.root[l] = (double)(float)a.hpd[(size_t)(HPD_ROOT0 + l) * nh + g];
   load_state<NN>(a, g, w);
   w.snow.vapor_flux = 0.; w.snow.canopy_vapor_flux = 0.;                  // full_energy.c:261-262
 
   const double wind_h = vl.f(veg_idx, VL_WIND_H);
   const double lai_cur = vl.f(veg_idx, VL_LAI + month - 1);
-  const double surf_atten = exp(-vl.f(veg_idx, VL_RAD_ATTEN) * lai_cur);   // full_energy.c:282
+  C.surf_atten = exp(-vl.f(veg_idx, VL_RAD_ATTEN) * lai_cur);   // full_energy.c:282
 
   // prepare_full_energy.c:8-94
-  double moist0 = w.moist[0] / (s3.depth[0] * 1000.), ice0 = 0.;
+  C.moist0 = w.moist[0] / (s3.depth[0] * 1000.); C.ice0 = 0.;
   if (o.FROZEN_SOIL && cv.s(CP_FS_ACTIVE) != 0.0) {
     const double tm = (w.nd.T[0] + w.nd.T[1]) / 2.;
     if (tm < 0.) {
-      ice0 = moist0 - maximum_unfrozen_water(tm, s3.max_moist[0] / (s3.depth[0] * 1000.), cv.lay(CPL_BUBBLE, 0), cv.lay(CPL_EXPT, 0));
-      if (ice0 < 0.) ice0 = 0.;
+      C.ice0 = C.moist0 - maximum_unfrozen_water(tm, s3.max_moist[0] / (s3.depth[0] * 1000.), cv.lay(CPL_BUBBLE, 0), cv.lay(CPL_EXPT, 0));
+      if (C.ice0 < 0.) C.ice0 = 0.;
     }
   }
   top_layer_thermal_properties(cv, s3, w.moist, w.ice, w.so.kappa, w.so.Cs);
-  const double bare_albedo = GLAC ? cv.s(CP_GLAC_ALBEDO) : vl.f(veg_idx, VL_ALBEDO + month - 1);
+  C.bare_albedo = GLAC ? cv.s(CP_GLAC_ALBEDO) : vl.f(veg_idx, VL_ALBEDO + month - 1);
 
   // aerodynamic resistances for the 6 PET surfaces and the current vegetation (full_energy.c:302-354)
-  Vc aero_pet[NPET], Ra, U, disp, zref, z0;
+  Vc& Ra = C.Ra; Vc& U = C.U; Vc& disp = C.disp; Vc& zref = C.zref; Vc& z0 = C.z0;
 #pragma unroll
   for (int k = 0; k < NCASE; k++) { disp.v[k] = NAN; zref.v[k] = NAN; z0.v[k] = NAN; U.v[k] = NAN; Ra.v[k] = NAN; }
   bool overstory = false;
@@ -285,46 +339,27 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
     if (!calc_aerodynamic(overstory, height, vl.f(pet_idx, VL_TRUNK_RATIO), snow_rough, rough, vl.f(pet_idx, VL_WIND_ATTEN), Ra, U,
                           disp, zref, z0))
       err |= VICGPU_CELLERR_AERO;
-    if (p < NPET) aero_pet[p] = Ra;
+    if (p < NPET) {
+#pragma unroll
+      for (int k = 0; k < NCASE; k++) C.aero_pet[p].v[k] = Ra.v[k];
+    }
   }
+  C.overstory = overstory ? 1 : 0;
   w.aero_resist_surface = Ra.v[SNOW_FREE];
   w.aero_resist_overstory = Ra.v[CANOPY];
 #pragma unroll
   for (int p = 0; p < NPET; p++) w.pot_evap[p] = 0;
+  return err;
+}
 
-  PROF_ADD(1, t_kernel);
-  if (!(err & VICGPU_CELLERR_AERO)) {
-    bool ok;
-    if constexpr (GLAC) {
-      GlacEnergy ge;
-      double nlu, nsu, sui;
-      ok = surface_fluxes_glac<NN>(o, cv, vl, s3, fc, dmy, veg_idx, band, bare_albedo, aero_pet, Ra, U, zref, z0, w, w.gl,
-                                   w.so.NetLongUnder, ge, nlu, nsu, sui);
-      // hru.energy = step_energy + step averages (surface_fluxes_glac.c:485-526)
-      SoilEnergy& so = w.so; SnowEnergy& se = w.se;
-      so.snow_flux = ge.snow_flux; so.grnd_flux = ge.grnd_flux; so.deltaH = 0; so.fusion = 0; so.LongUnderOut = ge.LongUnderOut;
-      so.AlbedoUnder = ge.AlbedoUnder; so.advected_sensible = ge.advected_sensible; so.advection = ge.advection;
-      so.deltaCC = ge.deltaCC; so.refreeze_energy = ge.refreeze_energy; so.error = ge.error; so.latent = ge.latent;
-      so.latent_sub = ge.latent_sub; so.sensible = ge.sensible; so.NetLongUnder = nlu; so.NetShortUnder = nsu; so.NetShortGrnd = 0;
-      se.canopy_advection = 0; se.canopy_latent = 0; se.canopy_latent_sub = 0; se.canopy_sensible = 0; se.canopy_refreeze = 0;
-      w.AlbedoOver_avg = 0; w.LongOverIn_avg = 0; w.NetLongOver_avg = 0; w.NetShortOver_avg = 0; w.ShortOverIn_avg = 0;
-      w.ShortUnderIn_avg = sui;
-      w.deltaCC_glac = ge.deltaCC_glac; w.glacier_flux = ge.glacier_flux; w.glacier_melt_energy = ge.glacier_melt_energy;
-      // accumulateGlacierMassBalance.c:13-67: the per-step += (the accumulation-window decision is driver state: the
-      // host makes cum_mass_balance valid when the window opens)
-      if (!isnan(w.gl.cum_mass_balance) && !isnan(w.gl.mass_balance)) w.gl.cum_mass_balance += w.gl.mass_balance;
-    } else {
-      ok = surface_fluxes<NN>(o, cv, vl, s3, fc, dmy, veg_idx, band, is_art_bare, overstory, bare_albedo, ice0, moist0, surf_atten,
-                              aero_pet, Ra, U, disp, zref, z0, root, w);
-    }
-    if (!ok) err |= VICGPU_CELLERR_SOLVER;
-  }
-
+// full_energy.c:437-455 and state / flux out
+template <int NN>
+VIC_DEV void hru_epilogue(const KArgs& a, int g, const CellView& cv, const Soil3& s3, const StepConst& C, HruWork<NN>& w, int err) {
   // root zone moisture and wetness (full_energy.c:437-455)
   w.rootmoist = 0; w.wetness = 0;
 #pragma unroll
   for (int l = 0; l < 3; l++) {
-    if (root[l] > 0) w.rootmoist += w.moist[l];
+    if (C.root[l] > 0) w.rootmoist += w.moist[l];
     w.wetness += (w.moist[l] - s3.Wpwp[l]) / (cv.lay(CPL_POROSITY, l) * s3.depth[l] * 1000 - s3.Wpwp[l]);
   }
   w.wetness /= 3;
@@ -340,9 +375,180 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
   store_flux<NN>(a, g, w);
   a.hru_err[g] = err;
   PROF_ADD(8, t_store);
+}
+
+// The whole HRU step in one lane: glacier HRUs (GLAC) and QUICK_FLUX (no soil-profile solve)
+template <int NN, bool GLAC>
+__global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= a.nhru) return;
+  const Opt& o = a.o;
+  const HruId id = hru_id(a, g);
+  // two instantiations share this body: GLAC = false handles ordinary HRUs (and writes the zero record of inactive
+  // ones), GLAC = true handles glacier HRUs; the domain numbering keeps either kind wave-uniform
+  if (id.is_glacier != GLAC && id.run) return;
+  if (!id.run) {
+    if (!GLAC) store_zero_record(a, g);
+    return;
+  }
+  PROF_T0(t_kernel);
+  CellView cv{a.cell_params, a.ncell, id.c, o.Nnode, o.Nband};
+  VegLib vl{a.veglib};
+  Forcing fc{a.forcing, a.snowflag, a.ncell, id.c, o.NR + 1};
+  const Soil3 s3 = load_soil3(cv);
+  HruWork<NN> w;
+  StepConst C;
+  int err = hru_prologue<NN, GLAC>(a, g, id, cv, vl, fc, s3, w, C);
+  PROF_ADD(1, t_kernel);
+
+  if (!(err & VICGPU_CELLERR_AERO)) {
+    bool ok;
+    if constexpr (GLAC) {
+      GlacEnergy ge;
+      double nlu, nsu, sui;
+      ok = surface_fluxes_glac<NN>(o, cv, vl, s3, fc, a.dmy, C.veg_idx, C.band, C.bare_albedo, C.aero_pet, C.Ra, C.U, C.zref, C.z0, w, w.gl,
+                                   w.so.NetLongUnder, ge, nlu, nsu, sui);
+      // hru.energy = step_energy + step averages (surface_fluxes_glac.c:485-526)
+      SoilEnergy& so = w.so; SnowEnergy& se = w.se;
+      so.snow_flux = ge.snow_flux; so.grnd_flux = ge.grnd_flux; so.deltaH = 0; so.fusion = 0; so.LongUnderOut = ge.LongUnderOut;
+      so.AlbedoUnder = ge.AlbedoUnder; so.advected_sensible = ge.advected_sensible; so.advection = ge.advection;
+      so.deltaCC = ge.deltaCC; so.refreeze_energy = ge.refreeze_energy; so.error = ge.error; so.latent = ge.latent;
+      so.latent_sub = ge.latent_sub; so.sensible = ge.sensible; so.NetLongUnder = nlu; so.NetShortUnder = nsu; so.NetShortGrnd = 0;
+      se.canopy_advection = 0; se.canopy_latent = 0; se.canopy_latent_sub = 0; se.canopy_sensible = 0; se.canopy_refreeze = 0;
+      w.AlbedoOver_avg = 0; w.LongOverIn_avg = 0; w.NetLongOver_avg = 0; w.NetShortOver_avg = 0; w.ShortOverIn_avg = 0;
+      w.ShortUnderIn_avg = sui;
+      w.deltaCC_glac = ge.deltaCC_glac; w.glacier_flux = ge.glacier_flux; w.glacier_melt_energy = ge.glacier_melt_energy;
+      // accumulateGlacierMassBalance.c:13-67: the per-step += (the accumulation-window decision is driver state: the
+      // host makes cum_mass_balance valid when the window opens)
+      if (!isnan(w.gl.cum_mass_balance) && !isnan(w.gl.mass_balance)) w.gl.cum_mass_balance += w.gl.mass_balance;
+    } else {
+      ok = surface_fluxes<NN>(o, cv, vl, s3, fc, a.dmy, C, w);
+    }
+    if (!ok) err |= VICGPU_CELLERR_SOLVER;
+  }
+  hru_epilogue<NN>(a, g, cv, s3, C, w, err);
   PROF_ADD(0, t_kernel);
   PROF_WAVE(0);
   PROF_LANE(1);
+}
+
+// Finite-difference pipeline, stage kernel: phase 0 starts the step of every ordinary HRU; phase p >= 1 resumes the
+// HRUs whose ground-surface root of sub-step p - 1 has been found.  Either way an HRU leaves with its next sub-step
+// set up and parked (appended to the work list) or with its step finished and stored.
+template <int NN>
+__global__ __launch_bounds__(64) void vic_fd_stage(const KArgs a) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= a.nhru) return;
+  const Opt& o = a.o;
+  const size_t nh = a.nhru;
+  const HruId id = hru_id(a, g);
+  if (id.run && id.is_glacier) return;              // vic_hru_step<NN, true> owns glacier HRUs
+  if (a.phase == 0 && !id.run) { store_zero_record(a, g); a.hstate[g] = 0; return; }
+  if (a.phase > 0 && a.hstate[g] != 2) return;
+  CellView cv{a.cell_params, a.ncell, id.c, o.Nnode, o.Nband};
+  VegLib vl{a.veglib};
+  Forcing fc{a.forcing, a.snowflag, a.ncell, id.c, o.NR + 1};
+  const Soil3 s3 = load_soil3(cv);
+  const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
+  HruWork<NN> w;
+  StepConst C;
+  SubLoop L;
+  int err = 0;
+  bool more;
+  if (a.phase == 0) {
+    err = hru_prologue<NN, false>(a, g, id, cv, vl, fc, s3, w, C);
+    more = !(err & VICGPU_CELLERR_AERO);
+    if (more) sf_begin<NN>(o, fc, C, w, L);
+  } else {
+    SubStep P;
+    SurfEB eb;
+    SurfSolve sv;
+    ctx_get(a.ctx + CO_SV * nh, nh, g, sv);
+    ctx_get(a.ctx + CO_EBM * nh, nh, g, static_cast<SurfEBMut&>(eb));
+    ctx_get(a.ctx + CO_EBC * nh, nh, g, static_cast<SurfEBConst&>(eb));
+    ctx_get(a.ctx + CO_P * nh, nh, g, P);
+    ctx_get(a.ctx + CO_L * nh, nh, g, L);
+    ctx_get(a.ctx + CO_C * nh, nh, g, C);
+    ctx_get(a.ctx + CO_W * nh, nh, g, w);
+    // the soil profile of the final evaluation
+    const double* __restrict__ po = a.pout + (size_t)g * pout_stride(Nn);
+    const int* __restrict__ poc = reinterpret_cast<const int*>(po + Nn + 1);
+    double Tprof[NN];
+    int cntprof[NN];
+    const unsigned long long flags = (unsigned long long)__double_as_longlong(po[Nn]);
+#pragma unroll
+    for (int n = 0; n < NN; n++) {
+      Tprof[n] = (n < Nn) ? po[n] : 0.0;
+      cntprof[n] = (n < Nn) ? poc[n] : 0;
+    }
+    sf_sub_post<NN>(o, cv, vl, s3, fc, a.dmy, C, w, L, P, eb, sv, Tprof, cntprof, (unsigned)(flags & 0xFFFFFFFFull));
+    more = true;
+  }
+  bool pend = false;
+  if (more && L.hidx < L.endhidx) {
+    SubStep P;
+    SurfEB eb;
+    SurfSolve sv;
+    sf_sub_pre<NN>(o, cv, vl, s3, fc, a.dmy, C, w, L, P, eb, sv);
+    profile_item_store<NN>(o, cv, s3, w.nd, eb.delta_t, eb.frozen_on != 0, a.pin + (size_t)g * Nn * PREC);
+    a.ts[g] = sv.x;
+    ctx_put(a.ctx + CO_SV * nh, nh, g, sv);
+    ctx_put(a.ctx + CO_EBM * nh, nh, g, static_cast<const SurfEBMut&>(eb));
+    ctx_put(a.ctx + CO_EBC * nh, nh, g, static_cast<const SurfEBConst&>(eb));
+    ctx_put(a.ctx + CO_P * nh, nh, g, P);
+    ctx_put(a.ctx + CO_L * nh, nh, g, L);
+    if (a.phase == 0) ctx_put(a.ctx + CO_C * nh, nh, g, C);
+    ctx_put(a.ctx + CO_W * nh, nh, g, w);
+    a.hstate[g] = 1;
+    pend = true;
+  } else {
+    if (more && !sf_end<NN>(o, cv, s3, C, w, L)) err |= VICGPU_CELLERR_SOLVER;
+    hru_epilogue<NN>(a, g, cv, s3, C, w, err);
+    a.hstate[g] = 0;
+  }
+  list_append(a.list, a.count, pend, g);
+}
+
+// Finite-difference pipeline, evaluation kernel: the residual of the ground-surface energy balance at the trial
+// temperature whose soil profile has just been solved, then one step of the Brent iteration on Tsurf.
+struct EArgs {
+  Opt o;
+  int ncell, nhru, Nn;
+  const double* cell_params;
+  const int* hpi;
+  unsigned long long* ctx;
+  const double* pout;
+  double* ts;
+  int* hstate;
+  int* list_next;
+  int* count_next;
+  int* profile_next;     // work-list cursor of the profile kernel, cleared for its next launch
+};
+
+__global__ __launch_bounds__(64) void vic_surf_eval(const EArgs a) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g == 0) *a.profile_next = 0;
+  if (g >= a.nhru) return;
+  if (a.hstate[g] != 1) return;
+  const size_t nh = a.nhru;
+  const int c = a.hpi[(size_t)HPI_CELL * nh + g];
+  CellView cv{a.cell_params, a.ncell, c, a.o.Nnode, a.o.Nband};
+  const Soil3 s3 = load_soil3(cv);
+  SurfSolve sv;
+  SurfEB eb;
+  ctx_get(a.ctx + CO_SV * nh, nh, g, sv);
+  ctx_get(a.ctx + CO_EBM * nh, nh, g, static_cast<SurfEBMut&>(eb));
+  ctx_get(a.ctx + CO_EBC * nh, nh, g, static_cast<SurfEBConst&>(eb));
+  const double* __restrict__ po = a.pout + (size_t)g * pout_stride(a.Nn);
+  const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
+  const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
+  surf_solve_consume(a.o, sv, eb, fx);
+  ctx_put(a.ctx + CO_SV * nh, nh, g, sv);
+  ctx_put(a.ctx + CO_EBM * nh, nh, g, static_cast<const SurfEBMut&>(eb));
+  const bool pend = sv.stage != SurfSolve::DONE;
+  if (pend) a.ts[g] = sv.x;
+  else a.hstate[g] = 2;
+  list_append(a.list_next, a.count_next, pend, g);
 }
 
 // ------------------------------------------------------------------------------------------------ cell kernel
@@ -423,30 +629,118 @@ struct vicgpu_ctx {
   int write_fluxes = 1;
   int steps_done = 0;
   bool any_glacier = false;
+  // finite-difference pipeline workspace (allocated when QUICK_FLUX is off)
+  bool fd = false;
+  unsigned long long* d_ctx = nullptr;
+  double *d_pin = nullptr, *d_ts = nullptr, *d_pout = nullptr;
+  int *d_hstate = nullptr, *d_list[2] = {nullptr, nullptr}, *d_count = nullptr;   // d_count[0..1] list sizes, [2] profile cursor
+  int profile_waves = 0;                                                           // resident waves of the profile kernel
+  int* h_count = nullptr;                                                          // pinned
+  long long fd_rounds = 0, fd_steps = 0;
 };
 
 static void free_domain(vicgpu_ctx* c) {
   void* ps[] = {c->d_cp, c->d_hpd, c->d_sd, c->d_flux, c->d_cell_out, c->d_accum, c->d_hpi, c->d_si, c->d_cell_off, c->d_cell_list,
-                c->d_hru_err, c->d_cell_err};
+                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_list[0], c->d_list[1], c->d_count};
   for (void* p : ps) HIPIGN(hipFree(p));
+  c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = c->d_list[0] = c->d_list[1] = c->d_count = nullptr;
   c->d_cp = c->d_hpd = c->d_sd = c->d_flux = c->d_cell_out = c->d_accum = nullptr;
   c->d_hpi = c->d_si = c->d_cell_off = c->d_cell_list = c->d_hru_err = c->d_cell_err = nullptr;
 }
 
 template <int NN>
-static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool any_glacier) {
+static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool ordinary, bool glacier) {
   const int nblk = (ka.nhru + 63) / 64;
-  const size_t lds = vic::prof_lds_bytes<NN>();    // node columns of the soil-profile solver, one slab per wave
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vic_hru_step<NN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vic_hru_step<NN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), lds, st, ka);
-  if (any_glacier) hipLaunchKernelGGL((vic_hru_step<NN, true>), dim3(nblk), dim3(64), lds, st, ka);
+  if (ordinary) hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), 0, st, ka);
+  if (glacier) hipLaunchKernelGGL((vic_hru_step<NN, true>), dim3(nblk), dim3(64), 0, st, ka);
   return hipGetLastError();
+}
+
+template <int NN>
+static hipError_t launch_fd_stage(const KArgs& ka, hipStream_t st) {
+  hipLaunchKernelGGL((vic_fd_stage<NN>), dim3((ka.nhru + 63) / 64), dim3(64), 0, st, ka);
+  return hipGetLastError();
+}
+
+template <int NN>
+static hipError_t launch_profile(const PArgs& pa, int nmax, int resident_waves, hipStream_t st) {
+  int nblk = (nmax + 63) / 64;
+  if (nblk > resident_waves) nblk = resident_waves;      // persistent waves pull from the work list
+  hipLaunchKernelGGL((vic_profile_solve<NN>), dim3(nblk), dim3(64), 0, st, pa);
+  return hipGetLastError();
+}
+
+template <int NN>
+static int profile_resident_waves(int device) {
+  int per_cu = 0, ncu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve<NN>, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+  return per_cu * ncu;
+}
+
+// One model step of the finite-difference pipeline (see the header of this file).  Blocks the host: the number of
+// Brent rounds is data dependent, so the pending count is read back once the first rounds are through.
+static int fd_read_count(vicgpu_ctx* c, int which, int* out) {
+  HIPCHK(c, hipMemcpyAsync(c->h_count, c->d_count + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = c->h_count[0];
+  return VICGPU_OK;
+}
+
+static int fd_step(vicgpu_ctx* c, KArgs ka) {
+  const int Nn = c->o.Nnode;
+  const bool n10 = (Nn == 10);
+  hipStream_t st = c->stream;
+  hipError_t e;
+  if (c->any_glacier) {
+    e = n10 ? launch_hru<10>(ka, st, false, true) : launch_hru<VIC_MAX_NODES>(ka, st, false, true);
+    HIPCHK(c, e);
+  }
+  HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(int) * 4, st));
+  int cur = 0;
+  ka.phase = 0; ka.list = c->d_list[cur]; ka.count = c->d_count + cur;
+  e = n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st);
+  HIPCHK(c, e);
+  PArgs pa;
+  pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
+  pa.TFALLBACK = c->o.TFALLBACK; pa.next = c->d_count + 2;
+  if (!c->profile_waves) c->profile_waves = n10 ? profile_resident_waves<10>(c->device) : profile_resident_waves<VIC_MAX_NODES>(c->device);
+  EArgs ea;
+  ea.o = c->o; ea.ncell = c->ncell; ea.nhru = c->nhru; ea.Nn = Nn; ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
+  ea.pout = c->d_pout; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = c->d_count + 2;
+  const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
+  const int nsub = c->o.NF;
+  for (int p = 1; p <= nsub; p++) {
+    int nmax = c->nhru;
+    for (int round = 0;; round++) {
+      pa.list = c->d_list[cur]; pa.count = c->d_count + cur; pa.count_zero = c->d_count + (cur ^ 1);
+      e = n10 ? launch_profile<10>(pa, nmax, c->profile_waves, st) : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, st);
+      HIPCHK(c, e);
+      ea.list_next = c->d_list[cur ^ 1]; ea.count_next = c->d_count + (cur ^ 1);
+      hipLaunchKernelGGL(vic_surf_eval, dim3((c->nhru + 63) / 64), dim3(64), 0, st, ea);
+      HIPCHK(c, hipGetLastError());
+      cur ^= 1;
+      c->fd_rounds++;
+      if (round + 1 >= FREE_ROUNDS) {
+        int n = 0;
+        const int r = fd_read_count(c, cur, &n);
+        if (r != VICGPU_OK) return r;
+        if (n == 0) break;
+        nmax = n;
+      }
+    }
+    ka.phase = p; ka.list = c->d_list[cur]; ka.count = c->d_count + cur;
+    e = n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st);
+    HIPCHK(c, e);
+    if (p < nsub) {
+      int n = 0;
+      const int r = fd_read_count(c, cur, &n);
+      if (r != VICGPU_OK) return r;
+      if (n == 0) break;
+    }
+  }
+  c->fd_steps++;
+  return VICGPU_OK;
 }
 
 extern "C" {
@@ -505,12 +799,15 @@ void vicgpu_destroy(vicgpu_ctx* c) {
   if (!c) return;
   HIPIGN(hipSetDevice(c->device));
   if (c->stream) HIPIGN(hipStreamSynchronize(c->stream));
+  if (getenv("VICGPU_STATS") && c->fd_steps)
+    fprintf(stderr, "[vicgpu] finite-difference pipeline: %lld steps, %.1f Brent rounds per step\n", c->fd_steps, (double)c->fd_rounds / c->fd_steps);
   free_domain(c);
   HIPIGN(hipFree(c->d_veglib)); HIPIGN(hipFree(c->d_forcing)); HIPIGN(hipFree(c->d_snowflag));
   for (auto e : c->ev) HIPIGN(hipEventDestroy(e));
   if (c->forcing_ready) HIPIGN(hipEventDestroy(c->forcing_ready));
   if (c->own_stream && c->stream) HIPIGN(hipStreamDestroy(c->stream));
   if (c->copy_stream) HIPIGN(hipStreamDestroy(c->copy_stream));
+  if (c->h_count) HIPIGN(hipHostFree(c->h_count));
   delete c;
 }
 
@@ -576,6 +873,23 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
   HIPCHK(c, hipMemset(c->d_accum, 0, sizeof(double) * CA_NROW * ncell));
   HIPCHK(c, hipMemset(c->d_hru_err, 0, sizeof(int) * nhru));
   HIPCHK(c, hipMemset(c->d_cell_err, 0, sizeof(int) * ncell));
+  c->fd = !c->o.QUICK_FLUX;
+  if (c->fd) {
+    const int Nn = c->o.Nnode;
+    const size_t words = (Nn == 10) ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
+    HIPCHK(c, hipMalloc(&c->d_ctx, sizeof(unsigned long long) * words * nhru));
+    HIPCHK(c, hipMalloc(&c->d_pin, sizeof(double) * (size_t)Nn * PREC * nhru));
+    HIPCHK(c, hipMalloc(&c->d_ts, sizeof(double) * nhru));
+    HIPCHK(c, hipMalloc(&c->d_pout, sizeof(double) * (size_t)pout_stride(Nn) * nhru));
+    HIPCHK(c, hipMalloc(&c->d_hstate, sizeof(int) * nhru));
+    HIPCHK(c, hipMalloc(&c->d_list[0], sizeof(int) * nhru));
+    HIPCHK(c, hipMalloc(&c->d_list[1], sizeof(int) * nhru));
+    HIPCHK(c, hipMalloc(&c->d_count, sizeof(int) * 4));
+    HIPCHK(c, hipMemset(c->d_hstate, 0, sizeof(int) * nhru));
+    HIPCHK(c, hipMemset(c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
+    HIPCHK(c, hipMemset(c->d_pout, 0, sizeof(double) * (size_t)pout_stride(Nn) * nhru));
+    if (!c->h_count) HIPCHK(c, hipHostMalloc(&c->h_count, sizeof(int) * 2, hipHostMallocDefault));
+  }
   return VICGPU_OK;
 }
 
@@ -643,6 +957,8 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   ka.o = c->o; ka.ncell = c->ncell; ka.nhru = c->nhru; ka.nveg_rows = c->nveg_rows; ka.write_fluxes = c->write_fluxes;
   ka.veglib = c->d_veglib; ka.cell_params = c->d_cp; ka.hpi = c->d_hpi; ka.hpd = c->d_hpd;
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
+  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.hstate = c->d_hstate; ka.list = nullptr; ka.count = nullptr;
+  ka.phase = 0;
   CArgs ca;
   ca.ncell = c->ncell; ca.nhru = c->nhru; ca.cell_off = c->d_cell_off; ca.cell_list = c->d_cell_list; ca.hpd = c->d_hpd;
   ca.hpi_glac = c->d_hpi + (size_t)HPI_IS_GLACIER * c->nhru;
@@ -656,10 +972,13 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
     ka.dmy.day = d[VIC_DMY_DAY]; ka.dmy.year = d[VIC_DMY_YEAR];
     HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0)], c->stream));
     hipError_t e;
-    if (c->o.Nnode == 3 && c->o.QUICK_FLUX) e = launch_hru<3>   /* <3> has no finite-difference profile solver */(ka, c->stream, c->any_glacier);
-    else if (c->o.Nnode == 10) e = launch_hru<10>(ka, c->stream, c->any_glacier);
-    else e = launch_hru<VIC_MAX_NODES>(ka, c->stream, c->any_glacier);
-    HIPCHK(c, e);
+    if (!c->fd) {
+      e = launch_hru<3>(ka, c->stream, true, c->any_glacier);      // QUICK_FLUX implies Nnode == 3 (vicgpu_create)
+      HIPCHK(c, e);
+    } else {
+      const int r = fd_step(c, ka);
+      if (r != VICGPU_OK) return r;
+    }
     HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0) + 1], c->stream));
     hipLaunchKernelGGL(vic_cell_reduce, dim3((c->ncell + 255) / 256), dim3(256), 0, c->stream, ca);
     HIPCHK(c, hipGetLastError());
