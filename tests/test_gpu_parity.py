@@ -47,6 +47,8 @@ CASES = {
     "frozen_fixed": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=0), 32, 3, 1),
     "frozen_compat": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=1), 32, 3, 1),
     "frozen_fixed_n8": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=8, frozen_compat=0), 32, 2, 300),
+    # water balance + frozen soil, daily with 3-hourly snow sub-steps: the pipeline re-enters the stage kernel per sub-step
+    "frozen_wb_daily": (dict(FULL_ENERGY=0, FROZEN_SOIL=1, Nnode=10, dt=24, snow_step=3, frozen_compat=0), 32, 2, 320),
     "glacier_winter": (dict(FULL_ENERGY=1, Nband=3, glacier=True), 32, 2, 1),
     "glacier_summer": (dict(FULL_ENERGY=1, Nband=3, glacier=True), 32, 2, 190),
     "glacier_frozen": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=2, frozen_compat=0, glacier=True), 32, 2, 120),
@@ -161,3 +163,24 @@ def test_water_balance_closes(oracle_lib):
     resid = (storage(sd1) - s0) - (acc[C["CA_PREC"]] - acc[C["CA_EVAP"]] - acc[C["CA_RUNOFF"]] - acc[C["CA_BASEFLOW"]])
     assert gpu.get_cell_errors().sum() == 0
     assert np.abs(resid).max() < 1e-6, np.abs(resid).max()
+
+
+def test_chunking_is_invisible(monkeypatch):
+    """The finite-difference pipeline splits the cells into chunks that run concurrently on their own streams and host
+    threads.  Cells never interact, so the chunk count must not change a single bit of the results."""
+    from vic_amd.api import Model
+    kw, ncell, ntile, doy = CASES["frozen_fixed"]
+    nsteps = 12
+    d, f, sf, dmy, sd0, si0 = _setup(kw, 200, ntile, nsteps, doy)
+    out = []
+    for nchunk in ("1", "3"):
+        monkeypatch.setenv("VICGPU_CHUNKS", nchunk)
+        m = Model(d)
+        m.set_state(sd0, si0)
+        m.push_forcing(f, sf, dmy)
+        m.dist_prec(0, nsteps)
+        sd, si = m.get_state()
+        out.append((sd, si, m.get_fluxes(), m.get_accum(), m.get_cell_errors()))
+        del m
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b, equal_nan=True)

@@ -41,6 +41,7 @@ SIDE_BY_SIDE = [
     ("frozen_fixed", dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=0), "fixed", 5, 3, False, 250, 280),
     ("frozen_fixed_noflux", dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=12, NOFLUX=1, frozen_compat=0), "fixed", 4, 2, False, 150, 1),
     ("frozen_compat", dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=1), "compat", 4, 2, False, 120, 330),
+    ("frozen_wb_daily", dict(FULL_ENERGY=0, FROZEN_SOIL=1, Nnode=10, dt=24, snow_step=3, frozen_compat=0), "fixed", 4, 2, False, 120, 300),
     ("glacier", dict(FULL_ENERGY=1, Nband=3), "plain", 6, 2, True, 500, 120),
     ("sntherm_sun1999", dict(FULL_ENERGY=1, SNOW_DENSITY=1, SNOW_ALBEDO=1), "plain", 6, 3, False, 300, 1),
     ("vic412_ar410", dict(FULL_ENERGY=1, TEMP_TH_TYPE=0, AERO_RESIST_CANSNOW=3), "plain", 6, 3, False, 300, 350),

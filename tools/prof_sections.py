@@ -10,12 +10,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-CYC = {0: "kernel total", 1: "load + prepare + aero", 2: "solve_snow", 3: "calc_surf_energy_bal", 4: "  solve_T_profile (in 3)",
+CYC = {0: "stage / monolithic kernel total", 1: "load + prepare + aero", 2: "solve_snow", 3: "root finder (monolithic)",
        5: "compute_pot_evap", 6: "runoff", 7: "zwt + distribute_node_moisture", 8: "store", 9: "  snow_intercept (in 2)",
-       10: "  snow_melt (in 2)"}
-CNT = {0: "waves", 1: "lanes", 2: "sub-steps (wave)", 4: "profile trips (wave)", 5: "profile trips (lane)", 6: "profile Brent evals (lane)",
+       10: "  snow_melt (in 2)", 11: "context get", 12: "sf_sub_post", 13: "sf_sub_pre (incl. solve_snow)", 14: "item block + context put",
+       15: "sf_end (incl. runoff, zwt)"}
+CNT = {0: "waves (stage launches)", 1: "lanes", 2: "sub-steps (wave)",
        7: "SurfEB evals (wave)", 8: "SurfEB evals (lane)", 9: "SnowPackEB evals (wave)", 10: "SnowPackEB evals (lane)",
-       11: "CanopyEB evals (wave)", 12: "CanopyEB evals (lane)"}
+       11: "CanopyEB evals (wave)", 12: "CanopyEB evals (lane)",
+       20: "profile kernel: wave trips", 21: "  lanes waiting at the gate", 22: "  lanes entering a node", 23: "  lanes in a Brent solve",
+       24: "  lanes idle (list exhausted)", 25: "  Brent lanes in the main iteration", 26: "gate openings", 27: "  lanes served per opening"}
 
 
 def main():
@@ -58,11 +61,6 @@ def main():
         print("  %-36s %14.0f cyc/wave  %5.1f %%" % (name, cyc[k] / max(cnt[0], 1), 100 * cyc[k] / tot))
     for k, name in CNT.items():
         print("  %-36s %14.0f" % (name, cnt[k]))
-    w = max(cnt[0], 1)
-    print("  per wave: sub-steps %.2f, SurfEB evals %.1f (lane mean %.1f), profile trips %.1f (lane mean %.1f, Brent evals/lane %.1f)" % (
-        cnt[2] / w, cnt[7] / w, cnt[8] / max(cnt[1], 1), cnt[4] / w, cnt[5] / max(cnt[1], 1), cnt[6] / max(cnt[1], 1)))
-    print("  per wave: SnowPackEB evals %.1f (lane mean %.1f), CanopyEB evals %.1f (lane mean %.1f)" % (
-        cnt[9] / w, cnt[10] / max(cnt[1], 1), cnt[11] / w, cnt[12] / max(cnt[1], 1)))
     if not args.prebuilt:
         vb.build(force=True)
 

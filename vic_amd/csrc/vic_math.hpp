@@ -337,10 +337,41 @@ VIC_DEV double volumetric_heat_capacity(double soil_fract, double water_fract, d
 }
 
 // soil_conduction.c:830-863
+// x^y for finite x > 0 as exp(y ln x): the freezing-point-depression curve is evaluated once per residual evaluation of
+// every frozen-node Brent solve, i.e. several hundred times per HRU and step, and the library pow spends ~250
+// instructions on corner cases that cannot occur here.  ln x follows the classic argument reduction
+// x = 2^k (1 + f), s = f / (2 + f), ln(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-14 minimax R of
+// fdlibm's e_log.c (error < 1 ulp); the result agrees with pow to a few ulp (|y ln x| < 40 here).
+VIC_DEV double ln_pos(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  int k;
+  double m = frexp(x, &k);                                  // m in [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? 2.0 * m : m;                              // m in [sqrt(1/2), sqrt(2))
+  k = lo ? k - 1 : k;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double dk = (double)k;
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+  const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+VIC_DEV double pow_pos(double x, double y) {
+  if (!(x > 0.0 && x < 1.0e300)) return pow(x, y);   // 0, negative, inf, NaN: the library's corner cases
+  return exp(y * ln_pos(x));
+}
+
 VIC_DEV double maximum_unfrozen_water(double T, double max_moist, double bubble, double expt) {
   double u;
   if (T <= 0) {
-    u = max_moist * pow((-LF * T) / 273.16 / (9.81 * bubble / 100.), -(2.0 / (expt - 3.0)));
+    u = max_moist * pow_pos((-LF * T) / 273.16 / (9.81 * bubble / 100.), -(2.0 / (expt - 3.0)));
     if (u > max_moist) u = max_moist;
     if (u < 0) u = 0;
   } else u = max_moist;

@@ -42,7 +42,6 @@ template <int NN>
 __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   __shared__ double Tl[NN * 64];      // current iterate  [node][lane]
   __shared__ double T0l[NN * 64];     // previous step    [node][lane]
-  __shared__ int cntl[NN * 64];       // fallbacks of the current solve [node][lane]
   const int lane = threadIdx.x;
   const int n = *a.count;
   if (blockIdx.x == 0 && lane == 0) *a.count_zero = 0;
@@ -54,7 +53,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   const double threshold = 1.e-2;
 #define TL(j) Tl[(j) * 64 + lane]
 #define T0L(j) T0l[(j) * 64 + lane]
-#define CNT(j) cntl[(j) * 64 + lane]
+#define CNT(j) outc[j]      // fallback counters of the current solve live in its output record (rarely touched)
 
   enum { NODE = 1, BRENT = 2, FINISH = 3, IDLE = 4 };   // FINISH: solve done (or nothing yet), waiting at the gate
   int mode = FINISH;
@@ -63,6 +62,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   unsigned fbmask = 0;
   double maxdiff = threshold, oldT = 0;
   const double* __restrict__ blk = a.pin;
+  int* __restrict__ outc = nullptr;
   Brent br;
   SoilThermalEqn eq;
   br.phase = Brent::DONE;
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
     const unsigned long long running = __ballot(mode == NODE || mode == BRENT);
     if (waiting == 0 && running == 0) break;             // every lane is IDLE
     if (waiting != 0 && (__popcll(waiting) >= PROFILE_GATE || running == 0)) {
+      PROF_WAVE(26); PROF_VOTE(27, mode == FINISH);
       if (mode == FINISH) {
         if (hru >= 0) {
           if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T[j]); Tlast == T0
@@ -98,10 +99,6 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
           for (int k = 0; k < NN; k++)
             if (k < Nn) out[k] = TL(k);
           out[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
-          int* __restrict__ outc = reinterpret_cast<int*>(out + Nn + 1);
-#pragma unroll
-          for (int k = 0; k < NN; k++)
-            if (k < Nn) outc[k] = CNT(k);
         }
         // next item: one atomic for all waiting lanes
         const int leader = __ffsll((long long)waiting) - 1;
@@ -112,6 +109,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         if (slot < n) {
           hru = a.list[slot];
           blk = a.pin + (size_t)hru * Nn * PREC;
+          outc = reinterpret_cast<int*>(a.pout + (size_t)hru * pout_stride(Nn) + Nn + 1);
           frozen_on = blk[PR_A] != 0.0;
           const double Ts = a.ts[hru];
 #pragma unroll
@@ -124,6 +122,8 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
       }
     }
     // ---- one unit of work per lane
+    PROF_WAVE(20); PROF_VOTE(21, mode == FINISH); PROF_VOTE(22, mode == NODE); PROF_VOTE(23, mode == BRENT); PROF_VOTE(24, mode == IDLE);
+    PROF_VOTE(25, mode == BRENT && br.phase == Brent::MAIN);
     bool node_done = false;
     double newT = 0;
     if (mode == NODE) {

@@ -76,11 +76,13 @@ VIC_DEV bool prof_leader() { return (int)__lane_id() == __ffsll((long long)__bal
     if (prof_leader()) atomicAdd(&vic_prof_cyc[id], (unsigned long long)_d); } while (0)
 #define PROF_LANE(id) atomicAdd(&vic_prof_cnt[id], 1ull)
 #define PROF_WAVE(id) do { if (prof_leader()) atomicAdd(&vic_prof_cnt[id], 1ull); } while (0)
+#define PROF_VOTE(id, pred) do { const unsigned long long m_ = __ballot(pred); if (prof_leader()) atomicAdd(&vic_prof_cnt[id], (unsigned long long)__popcll(m_)); } while (0)
 #else
 #define PROF_T0(name) do { } while (0)
 #define PROF_ADD(id, name) do { } while (0)
 #define PROF_LANE(id) do { } while (0)
 #define PROF_WAVE(id) do { } while (0)
+#define PROF_VOTE(id, pred) do { } while (0)
 #endif
 
 VIC_DEV bool is_error(double x) { return x <= -998.0; }   // RootBrent::resultIsError

@@ -14,7 +14,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "vicgpu.h"
 #include <type_traits>
@@ -47,8 +50,10 @@ struct KArgs {
   int* si;
   double* flux;
   int* hru_err;                     // [nhru]
+  const int* glist;                 // HRUs of this launch (a cell chunk), or null: all HRUs in order
+  int gcount;
   // finite-difference pipeline only (null otherwise)
-  unsigned long long* ctx;          // parked per-HRU context, [word][nhru]
+  unsigned long long* ctx;          // parked per-HRU context, [hru / 64][word][hru % 64]
   double* pin;                      // profile item blocks [nhru][Nn][PREC]
   double* ts;                       // trial surface temperature [nhru]
   const double* pout;               // profile solutions [nhru][pout_stride(Nn)]
@@ -59,23 +64,33 @@ struct KArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ parked context
-// Plain structs are parked word by word in a [word][nhru] table (coalesced for lanes = consecutive HRUs).
+// Plain structs are parked word by word.  The table is tiled by wave: [hru / 64][word][hru % 64], so one wave's whole
+// context is a single contiguous slab (coalesced 512-byte rows, a handful of pages) instead of one row per word
+// spread over the whole table.
+struct CtxRef {
+  unsigned long long* p;    // slab of this lane's wave, offset by the lane
+  VIC_DEV static CtxRef at(unsigned long long* base, size_t words_per_hru, size_t g) {
+    return CtxRef{base + (g >> 6) * (words_per_hru * 64) + (g & 63)};
+  }
+};
 template <class T>
-VIC_DEV void ctx_put(unsigned long long* __restrict__ base, size_t nh, size_t g, const T& v) {
+VIC_DEV void ctx_put(const CtxRef& r, size_t word0, const T& v) {
   static_assert(sizeof(T) % 8 == 0 && std::is_trivially_copyable<T>::value, "context structs are arrays of 8-byte words");
   constexpr int NW = sizeof(T) / 8;
   unsigned long long tmp[NW];
   __builtin_memcpy(tmp, &v, sizeof(T));
+  unsigned long long* __restrict__ q = r.p + word0 * 64;
 #pragma unroll
-  for (int i = 0; i < NW; i++) base[(size_t)i * nh + g] = tmp[i];
+  for (int i = 0; i < NW; i++) q[(size_t)i * 64] = tmp[i];
 }
 template <class T>
-VIC_DEV void ctx_get(const unsigned long long* __restrict__ base, size_t nh, size_t g, T& v) {
+VIC_DEV void ctx_get(const CtxRef& r, size_t word0, T& v) {
   static_assert(sizeof(T) % 8 == 0 && std::is_trivially_copyable<T>::value, "context structs are arrays of 8-byte words");
   constexpr int NW = sizeof(T) / 8;
   unsigned long long tmp[NW];
+  const unsigned long long* __restrict__ q = r.p + word0 * 64;
 #pragma unroll
-  for (int i = 0; i < NW; i++) tmp[i] = base[(size_t)i * nh + g];
+  for (int i = 0; i < NW; i++) tmp[i] = q[(size_t)i * 64];
   __builtin_memcpy(&v, tmp, sizeof(T));
 }
 constexpr size_t CW_SV = sizeof(SurfSolve) / 8, CW_EBM = sizeof(SurfEBMut) / 8, CW_EBC = sizeof(SurfEBConst) / 8,
@@ -380,8 +395,9 @@ VIC_DEV void hru_epilogue(const KArgs& a, int g, const CellView& cv, const Soil3
 // The whole HRU step in one lane: glacier HRUs (GLAC) and QUICK_FLUX (no soil-profile solve)
 template <int NN, bool GLAC>
 __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
-  const int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= a.nhru) return;
+  const int gi = blockIdx.x * 64 + threadIdx.x;
+  if (gi >= a.gcount) return;
+  const int g = a.glist ? a.glist[gi] : gi;
   const Opt& o = a.o;
   const HruId id = hru_id(a, g);
   // two instantiations share this body: GLAC = false handles ordinary HRUs (and writes the zero record of inactive
@@ -436,9 +452,10 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
 // HRUs whose ground-surface root of sub-step p - 1 has been found.  Either way an HRU leaves with its next sub-step
 // set up and parked (appended to the work list) or with its step finished and stored.
 template <int NN>
-__global__ __launch_bounds__(64) void vic_fd_stage(const KArgs a) {
-  const int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= a.nhru) return;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void vic_fd_stage(const KArgs a) {
+  const int gi = blockIdx.x * 64 + threadIdx.x;
+  if (gi >= a.gcount) return;
+  const int g = a.glist ? a.glist[gi] : gi;
   const Opt& o = a.o;
   const size_t nh = a.nhru;
   const HruId id = hru_id(a, g);
@@ -450,26 +467,31 @@ __global__ __launch_bounds__(64) void vic_fd_stage(const KArgs a) {
   Forcing fc{a.forcing, a.snowflag, a.ncell, id.c, o.NR + 1};
   const Soil3 s3 = load_soil3(cv);
   const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
+  const CtxRef cx = CtxRef::at(a.ctx, ctx_words<NN>(), g);
   HruWork<NN> w;
   StepConst C;
   SubLoop L;
   int err = 0;
   bool more;
+  PROF_T0(t_stage);
   if (a.phase == 0) {
     err = hru_prologue<NN, false>(a, g, id, cv, vl, fc, s3, w, C);
+    PROF_ADD(1, t_stage);
     more = !(err & VICGPU_CELLERR_AERO);
     if (more) sf_begin<NN>(o, fc, C, w, L);
   } else {
     SubStep P;
     SurfEB eb;
     SurfSolve sv;
-    ctx_get(a.ctx + CO_SV * nh, nh, g, sv);
-    ctx_get(a.ctx + CO_EBM * nh, nh, g, static_cast<SurfEBMut&>(eb));
-    ctx_get(a.ctx + CO_EBC * nh, nh, g, static_cast<SurfEBConst&>(eb));
-    ctx_get(a.ctx + CO_P * nh, nh, g, P);
-    ctx_get(a.ctx + CO_L * nh, nh, g, L);
-    ctx_get(a.ctx + CO_C * nh, nh, g, C);
-    ctx_get(a.ctx + CO_W * nh, nh, g, w);
+    ctx_get(cx, CO_SV, sv);
+    ctx_get(cx, CO_EBM, static_cast<SurfEBMut&>(eb));
+    ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
+    ctx_get(cx, CO_P, P);
+    ctx_get(cx, CO_L, L);
+    ctx_get(cx, CO_C, C);
+    ctx_get(cx, CO_W, w);
+    PROF_ADD(11, t_stage);
+    PROF_T0(t_post);
     // the soil profile of the final evaluation
     const double* __restrict__ po = a.pout + (size_t)g * pout_stride(Nn);
     const int* __restrict__ poc = reinterpret_cast<const int*>(po + Nn + 1);
@@ -482,6 +504,7 @@ __global__ __launch_bounds__(64) void vic_fd_stage(const KArgs a) {
       cntprof[n] = (n < Nn) ? poc[n] : 0;
     }
     sf_sub_post<NN>(o, cv, vl, s3, fc, a.dmy, C, w, L, P, eb, sv, Tprof, cntprof, (unsigned)(flags & 0xFFFFFFFFull));
+    PROF_ADD(12, t_post);
     more = true;
   }
   bool pend = false;
@@ -489,24 +512,33 @@ __global__ __launch_bounds__(64) void vic_fd_stage(const KArgs a) {
     SubStep P;
     SurfEB eb;
     SurfSolve sv;
+    PROF_T0(t_pre);
     sf_sub_pre<NN>(o, cv, vl, s3, fc, a.dmy, C, w, L, P, eb, sv);
+    PROF_ADD(13, t_pre);
+    PROF_T0(t_put);
     profile_item_store<NN>(o, cv, s3, w.nd, eb.delta_t, eb.frozen_on != 0, a.pin + (size_t)g * Nn * PREC);
     a.ts[g] = sv.x;
-    ctx_put(a.ctx + CO_SV * nh, nh, g, sv);
-    ctx_put(a.ctx + CO_EBM * nh, nh, g, static_cast<const SurfEBMut&>(eb));
-    ctx_put(a.ctx + CO_EBC * nh, nh, g, static_cast<const SurfEBConst&>(eb));
-    ctx_put(a.ctx + CO_P * nh, nh, g, P);
-    ctx_put(a.ctx + CO_L * nh, nh, g, L);
-    if (a.phase == 0) ctx_put(a.ctx + CO_C * nh, nh, g, C);
-    ctx_put(a.ctx + CO_W * nh, nh, g, w);
+    ctx_put(cx, CO_SV, sv);
+    ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
+    ctx_put(cx, CO_EBC, static_cast<const SurfEBConst&>(eb));
+    ctx_put(cx, CO_P, P);
+    ctx_put(cx, CO_L, L);
+    if (a.phase == 0) ctx_put(cx, CO_C, C);
+    ctx_put(cx, CO_W, w);
     a.hstate[g] = 1;
     pend = true;
+    PROF_ADD(14, t_put);
   } else {
+    PROF_T0(t_end);
     if (more && !sf_end<NN>(o, cv, s3, C, w, L)) err |= VICGPU_CELLERR_SOLVER;
+    PROF_ADD(15, t_end);
     hru_epilogue<NN>(a, g, cv, s3, C, w, err);
     a.hstate[g] = 0;
   }
   list_append(a.list, a.count, pend, g);
+  PROF_ADD(0, t_stage);
+  PROF_WAVE(0);
+  PROF_LANE(1);
 }
 
 // Finite-difference pipeline, evaluation kernel: the residual of the ground-surface energy balance at the trial
@@ -514,9 +546,12 @@ __global__ __launch_bounds__(64) void vic_fd_stage(const KArgs a) {
 struct EArgs {
   Opt o;
   int ncell, nhru, Nn;
+  const int* glist;
+  int gcount;
   const double* cell_params;
   const int* hpi;
   unsigned long long* ctx;
+  size_t ctx_words;
   const double* pout;
   double* ts;
   int* hstate;
@@ -525,10 +560,11 @@ struct EArgs {
   int* profile_next;     // work-list cursor of the profile kernel, cleared for its next launch
 };
 
-__global__ __launch_bounds__(64) void vic_surf_eval(const EArgs a) {
-  const int g = blockIdx.x * 64 + threadIdx.x;
-  if (g == 0) *a.profile_next = 0;
-  if (g >= a.nhru) return;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vic_surf_eval(const EArgs a) {
+  const int gi = blockIdx.x * 64 + threadIdx.x;
+  if (gi == 0) *a.profile_next = 0;
+  if (gi >= a.gcount) return;
+  const int g = a.glist ? a.glist[gi] : gi;
   if (a.hstate[g] != 1) return;
   const size_t nh = a.nhru;
   const int c = a.hpi[(size_t)HPI_CELL * nh + g];
@@ -536,15 +572,16 @@ __global__ __launch_bounds__(64) void vic_surf_eval(const EArgs a) {
   const Soil3 s3 = load_soil3(cv);
   SurfSolve sv;
   SurfEB eb;
-  ctx_get(a.ctx + CO_SV * nh, nh, g, sv);
-  ctx_get(a.ctx + CO_EBM * nh, nh, g, static_cast<SurfEBMut&>(eb));
-  ctx_get(a.ctx + CO_EBC * nh, nh, g, static_cast<SurfEBConst&>(eb));
+  const CtxRef cx = CtxRef::at(a.ctx, a.ctx_words, g);
+  ctx_get(cx, CO_SV, sv);
+  ctx_get(cx, CO_EBM, static_cast<SurfEBMut&>(eb));
+  ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
   const double* __restrict__ po = a.pout + (size_t)g * pout_stride(a.Nn);
   const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
   const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
   surf_solve_consume(a.o, sv, eb, fx);
-  ctx_put(a.ctx + CO_SV * nh, nh, g, sv);
-  ctx_put(a.ctx + CO_EBM * nh, nh, g, static_cast<const SurfEBMut&>(eb));
+  ctx_put(cx, CO_SV, sv);
+  ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
   const bool pend = sv.stage != SurfSolve::DONE;
   if (pend) a.ts[g] = sv.x;
   else a.hstate[g] = 2;
@@ -554,6 +591,7 @@ __global__ __launch_bounds__(64) void vic_surf_eval(const EArgs a) {
 // ------------------------------------------------------------------------------------------------ cell kernel
 struct CArgs {
   int ncell, nhru;
+  int c0, ccount;        // cells of this launch
   const int* cell_off;
   const int* cell_list;
   const double* hpd;
@@ -567,8 +605,9 @@ struct CArgs {
 };
 
 __global__ __launch_bounds__(256) void vic_cell_reduce(const CArgs a) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.ncell) return;
+  const int ci = blockIdx.x * 256 + threadIdx.x;
+  if (ci >= a.ccount) return;
+  const int c = a.c0 + ci;
   const size_t nh = a.nhru, nc = a.ncell;
   double op = 0, orn = 0, os = 0, ro = 0, bf = 0, ev = 0, swe = 0, sm0 = 0, sm1 = 0, sm2 = 0, gmb = 0;
   int err = 0;
@@ -608,6 +647,23 @@ __global__ __launch_bounds__(256) void vic_cell_reduce(const CArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ context
+// A chunk of cells with all their HRUs.  Cells never interact, so every chunk runs the whole step sequence on its own
+// stream, driven by its own host thread: while one chunk is in the thin tail of its Brent rounds (a few stragglers,
+// latency bound) or in a stage kernel (memory / latency bound), the profile solves of the others fill the SIMDs.
+struct FdChunk {
+  int c0 = 0, ccount = 0;          // cells [c0, c0 + ccount)
+  int* d_glist = nullptr;          // their HRUs, ascending
+  int gcount = 0;
+  int* d_list[2] = {nullptr, nullptr};   // work lists (HRU ids)
+  int* d_count = nullptr;          // [0..1] list sizes, [2] profile-kernel cursor
+  int* h_count = nullptr;          // pinned read-back
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  std::string err;
+  int status = 0;
+  long long rounds = 0, steps = 0;
+};
+
 struct vicgpu_ctx {
   vicgpu_options opt;
   Opt o;
@@ -633,24 +689,31 @@ struct vicgpu_ctx {
   bool fd = false;
   unsigned long long* d_ctx = nullptr;
   double *d_pin = nullptr, *d_ts = nullptr, *d_pout = nullptr;
-  int *d_hstate = nullptr, *d_list[2] = {nullptr, nullptr}, *d_count = nullptr;   // d_count[0..1] list sizes, [2] profile cursor
-  int profile_waves = 0;                                                           // resident waves of the profile kernel
-  int* h_count = nullptr;                                                          // pinned
-  long long fd_rounds = 0, fd_steps = 0;
+  int* d_hstate = nullptr;
+  int profile_waves = 0;           // resident waves of the profile kernel
+  std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
+  int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
 };
 
 static void free_domain(vicgpu_ctx* c) {
   void* ps[] = {c->d_cp, c->d_hpd, c->d_sd, c->d_flux, c->d_cell_out, c->d_accum, c->d_hpi, c->d_si, c->d_cell_off, c->d_cell_list,
-                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_list[0], c->d_list[1], c->d_count};
+                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate};
   for (void* p : ps) HIPIGN(hipFree(p));
-  c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = c->d_list[0] = c->d_list[1] = c->d_count = nullptr;
+  for (FdChunk& ch : c->chunks) {
+    HIPIGN(hipFree(ch.d_glist)); HIPIGN(hipFree(ch.d_list[0])); HIPIGN(hipFree(ch.d_list[1])); HIPIGN(hipFree(ch.d_count));
+    if (ch.h_count) HIPIGN(hipHostFree(ch.h_count));
+    if (ch.done) HIPIGN(hipEventDestroy(ch.done));
+    if (ch.stream) HIPIGN(hipStreamDestroy(ch.stream));
+  }
+  c->chunks.clear();
+  c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = nullptr;
   c->d_cp = c->d_hpd = c->d_sd = c->d_flux = c->d_cell_out = c->d_accum = nullptr;
   c->d_hpi = c->d_si = c->d_cell_off = c->d_cell_list = c->d_hru_err = c->d_cell_err = nullptr;
 }
 
 template <int NN>
 static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool ordinary, bool glacier) {
-  const int nblk = (ka.nhru + 63) / 64;
+  const int nblk = (ka.gcount + 63) / 64;
   if (ordinary) hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), 0, st, ka);
   if (glacier) hipLaunchKernelGGL((vic_hru_step<NN, true>), dim3(nblk), dim3(64), 0, st, ka);
   return hipGetLastError();
@@ -658,7 +721,7 @@ static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool ordinary, boo
 
 template <int NN>
 static hipError_t launch_fd_stage(const KArgs& ka, hipStream_t st) {
-  hipLaunchKernelGGL((vic_fd_stage<NN>), dim3((ka.nhru + 63) / 64), dim3(64), 0, st, ka);
+  hipLaunchKernelGGL((vic_fd_stage<NN>), dim3((ka.gcount + 63) / 64), dim3(64), 0, st, ka);
   return hipGetLastError();
 }
 
@@ -678,68 +741,108 @@ static int profile_resident_waves(int device) {
   return per_cu * ncu;
 }
 
-// One model step of the finite-difference pipeline (see the header of this file).  Blocks the host: the number of
-// Brent rounds is data dependent, so the pending count is read back once the first rounds are through.
-static int fd_read_count(vicgpu_ctx* c, int which, int* out) {
-  HIPCHK(c, hipMemcpyAsync(c->h_count, c->d_count + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  *out = c->h_count[0];
+#define CHKCH(ch, call)                                                                               \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      (ch)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                   \
+      return VICGPU_ERR_HIP;                                                                           \
+    }                                                                                                  \
+  } while (0)
+
+// One model step of the finite-difference pipeline for one chunk (see the header of this file).  Blocks the calling
+// host thread: the number of Brent rounds is data dependent, so the pending count is read back once the first rounds
+// are through.
+static int fd_read_count(FdChunk* ch, int which, int* out) {
+  CHKCH(ch, hipMemcpyAsync(ch->h_count, ch->d_count + which, sizeof(int), hipMemcpyDeviceToHost, ch->stream));
+  CHKCH(ch, hipStreamSynchronize(ch->stream));
+  *out = ch->h_count[0];
   return VICGPU_OK;
 }
 
-static int fd_step(vicgpu_ctx* c, KArgs ka) {
+static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   const int Nn = c->o.Nnode;
   const bool n10 = (Nn == 10);
-  hipStream_t st = c->stream;
-  hipError_t e;
-  if (c->any_glacier) {
-    e = n10 ? launch_hru<10>(ka, st, false, true) : launch_hru<VIC_MAX_NODES>(ka, st, false, true);
-    HIPCHK(c, e);
-  }
-  HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(int) * 4, st));
+  hipStream_t st = ch->stream;
+  if (c->any_glacier) CHKCH(ch, (n10 ? launch_hru<10>(ka, st, false, true) : launch_hru<VIC_MAX_NODES>(ka, st, false, true)));
+  CHKCH(ch, hipMemsetAsync(ch->d_count, 0, sizeof(int) * 4, st));
   int cur = 0;
-  ka.phase = 0; ka.list = c->d_list[cur]; ka.count = c->d_count + cur;
-  e = n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st);
-  HIPCHK(c, e);
+  ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur;
+  CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st)));
   PArgs pa;
   pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
-  pa.TFALLBACK = c->o.TFALLBACK; pa.next = c->d_count + 2;
-  if (!c->profile_waves) c->profile_waves = n10 ? profile_resident_waves<10>(c->device) : profile_resident_waves<VIC_MAX_NODES>(c->device);
+  pa.TFALLBACK = c->o.TFALLBACK; pa.next = ch->d_count + 2;
   EArgs ea;
-  ea.o = c->o; ea.ncell = c->ncell; ea.nhru = c->nhru; ea.Nn = Nn; ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
-  ea.pout = c->d_pout; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = c->d_count + 2;
+  ea.o = c->o; ea.ncell = c->ncell; ea.nhru = c->nhru; ea.Nn = Nn; ea.glist = ch->d_glist; ea.gcount = ch->gcount;
+  ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
+  ea.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
+  ea.pout = c->d_pout; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + 2;
   const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
-    int nmax = c->nhru;
+    int nmax = ch->gcount;
     for (int round = 0;; round++) {
-      pa.list = c->d_list[cur]; pa.count = c->d_count + cur; pa.count_zero = c->d_count + (cur ^ 1);
-      e = n10 ? launch_profile<10>(pa, nmax, c->profile_waves, st) : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, st);
-      HIPCHK(c, e);
-      ea.list_next = c->d_list[cur ^ 1]; ea.count_next = c->d_count + (cur ^ 1);
-      hipLaunchKernelGGL(vic_surf_eval, dim3((c->nhru + 63) / 64), dim3(64), 0, st, ea);
-      HIPCHK(c, hipGetLastError());
+      pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur; pa.count_zero = ch->d_count + (cur ^ 1);
+      CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, st) : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, st)));
+      ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1);
+      hipLaunchKernelGGL(vic_surf_eval, dim3((ch->gcount + 63) / 64), dim3(64), 0, st, ea);
+      CHKCH(ch, hipGetLastError());
       cur ^= 1;
-      c->fd_rounds++;
+      ch->rounds++;
       if (round + 1 >= FREE_ROUNDS) {
         int n = 0;
-        const int r = fd_read_count(c, cur, &n);
+        const int r = fd_read_count(ch, cur, &n);
         if (r != VICGPU_OK) return r;
         if (n == 0) break;
         nmax = n;
       }
     }
-    ka.phase = p; ka.list = c->d_list[cur]; ka.count = c->d_count + cur;
-    e = n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st);
-    HIPCHK(c, e);
+    ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur;
+    CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st)));
     if (p < nsub) {
       int n = 0;
-      const int r = fd_read_count(c, cur, &n);
+      const int r = fd_read_count(ch, cur, &n);
       if (r != VICGPU_OK) return r;
       if (n == 0) break;
     }
   }
-  c->fd_steps++;
+  ch->steps++;
+  return VICGPU_OK;
+}
+
+struct StepPlan {
+  vicgpu_ctx* c;
+  KArgs ka;
+  CArgs ca;
+  int step0, nsteps;
+};
+
+
+static void set_step_inputs(const vicgpu_ctx* c, KArgs& ka, int s) {
+  const size_t nsub = c->o.NR + 1;
+  ka.forcing = c->d_forcing + (size_t)s * VIC_NFORCE * nsub * c->ncell;
+  ka.snowflag = c->d_snowflag + (size_t)s * nsub * c->ncell;
+  const int* d = &c->dmy[(size_t)s * VIC_NDMY];
+  ka.dmy.month = d[VIC_DMY_MONTH]; ka.dmy.day_in_year = d[VIC_DMY_DAY_IN_YEAR]; ka.dmy.hour = d[VIC_DMY_HOUR];
+  ka.dmy.day = d[VIC_DMY_DAY]; ka.dmy.year = d[VIC_DMY_YEAR];
+}
+
+// all steps of one vicgpu_step call for one chunk
+static int fd_chunk_run(const StepPlan& plan, FdChunk* ch) {
+  vicgpu_ctx* c = plan.c;
+  CHKCH(ch, hipSetDevice(c->device));
+  KArgs ka = plan.ka;
+  CArgs ca = plan.ca;
+  ka.glist = ch->d_glist; ka.gcount = ch->gcount;
+  ca.c0 = ch->c0; ca.ccount = ch->ccount;
+  for (int s = plan.step0; s < plan.step0 + plan.nsteps; s++) {
+    set_step_inputs(c, ka, s);
+    const int r = fd_step(c, ch, ka);
+    if (r != VICGPU_OK) return r;
+    hipLaunchKernelGGL(vic_cell_reduce, dim3((ch->ccount + 255) / 256), dim3(256), 0, ch->stream, ca);
+    CHKCH(ch, hipGetLastError());
+  }
+  CHKCH(ch, hipEventRecord(ch->done, ch->stream));
   return VICGPU_OK;
 }
 
@@ -799,15 +902,17 @@ void vicgpu_destroy(vicgpu_ctx* c) {
   if (!c) return;
   HIPIGN(hipSetDevice(c->device));
   if (c->stream) HIPIGN(hipStreamSynchronize(c->stream));
-  if (getenv("VICGPU_STATS") && c->fd_steps)
-    fprintf(stderr, "[vicgpu] finite-difference pipeline: %lld steps, %.1f Brent rounds per step\n", c->fd_steps, (double)c->fd_rounds / c->fd_steps);
+  if (getenv("VICGPU_STATS"))
+    for (size_t k = 0; k < c->chunks.size(); k++)
+      if (c->chunks[k].steps)
+        fprintf(stderr, "[vicgpu] chunk %zu: %d cells, %d HRUs, %lld steps, %.1f Brent rounds per step\n", k, c->chunks[k].ccount,
+                c->chunks[k].gcount, c->chunks[k].steps, (double)c->chunks[k].rounds / c->chunks[k].steps);
   free_domain(c);
   HIPIGN(hipFree(c->d_veglib)); HIPIGN(hipFree(c->d_forcing)); HIPIGN(hipFree(c->d_snowflag));
   for (auto e : c->ev) HIPIGN(hipEventDestroy(e));
   if (c->forcing_ready) HIPIGN(hipEventDestroy(c->forcing_ready));
   if (c->own_stream && c->stream) HIPIGN(hipStreamDestroy(c->stream));
   if (c->copy_stream) HIPIGN(hipStreamDestroy(c->copy_stream));
-  if (c->h_count) HIPIGN(hipHostFree(c->h_count));
   delete c;
 }
 
@@ -877,18 +982,40 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
   if (c->fd) {
     const int Nn = c->o.Nnode;
     const size_t words = (Nn == 10) ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
-    HIPCHK(c, hipMalloc(&c->d_ctx, sizeof(unsigned long long) * words * nhru));
+    HIPCHK(c, hipMalloc(&c->d_ctx, sizeof(unsigned long long) * words * (((size_t)nhru + 63) / 64 * 64)));
     HIPCHK(c, hipMalloc(&c->d_pin, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, hipMalloc(&c->d_ts, sizeof(double) * nhru));
     HIPCHK(c, hipMalloc(&c->d_pout, sizeof(double) * (size_t)pout_stride(Nn) * nhru));
     HIPCHK(c, hipMalloc(&c->d_hstate, sizeof(int) * nhru));
-    HIPCHK(c, hipMalloc(&c->d_list[0], sizeof(int) * nhru));
-    HIPCHK(c, hipMalloc(&c->d_list[1], sizeof(int) * nhru));
-    HIPCHK(c, hipMalloc(&c->d_count, sizeof(int) * 4));
     HIPCHK(c, hipMemset(c->d_hstate, 0, sizeof(int) * nhru));
     HIPCHK(c, hipMemset(c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, hipMemset(c->d_pout, 0, sizeof(double) * (size_t)pout_stride(Nn) * nhru));
-    if (!c->h_count) HIPCHK(c, hipHostMalloc(&c->h_count, sizeof(int) * 2, hipHostMallocDefault));
+    c->profile_waves = (Nn == 10) ? profile_resident_waves<10>(c->device) : profile_resident_waves<VIC_MAX_NODES>(c->device);
+    // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  One chunk is the
+    // default: the persistent profile kernel fills every SIMD, so concurrent chunks mostly queue behind each other.
+    int nchunk = 1;
+    if (const char* ev = getenv("VICGPU_CHUNKS")) nchunk = atoi(ev);
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > 16) nchunk = 16;
+    if (nchunk > ncell) nchunk = ncell;
+    c->chunks.resize(nchunk);
+    for (int k = 0; k < nchunk; k++) {
+      FdChunk& ch = c->chunks[k];
+      ch.c0 = (int)((long long)ncell * k / nchunk);
+      ch.ccount = (int)((long long)ncell * (k + 1) / nchunk) - ch.c0;
+      std::vector<int> gl(cell_hru_list + cell_hru_offset[ch.c0], cell_hru_list + cell_hru_offset[ch.c0 + ch.ccount]);
+      std::sort(gl.begin(), gl.end());
+      ch.gcount = (int)gl.size();
+      const size_t gb = sizeof(int) * (size_t)(ch.gcount > 0 ? ch.gcount : 1);
+      HIPCHK(c, hipMalloc(&ch.d_glist, gb));
+      HIPCHK(c, hipMalloc(&ch.d_list[0], gb));
+      HIPCHK(c, hipMalloc(&ch.d_list[1], gb));
+      HIPCHK(c, hipMalloc(&ch.d_count, sizeof(int) * 4));
+      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * 2, hipHostMallocDefault));
+      if (ch.gcount) HIPCHK(c, hipMemcpy(ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
+      HIPCHK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
+    }
   }
   return VICGPU_OK;
 }
@@ -952,39 +1079,64 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
     c->ev.push_back(e);
   }
   c->ev_used = 0;
-  const size_t nsub = c->o.NR + 1;
-  KArgs ka;
+  c->ev_steps = 0;
+  StepPlan plan;
+  plan.c = c; plan.step0 = step0; plan.nsteps = nsteps;
+  KArgs& ka = plan.ka;
   ka.o = c->o; ka.ncell = c->ncell; ka.nhru = c->nhru; ka.nveg_rows = c->nveg_rows; ka.write_fluxes = c->write_fluxes;
   ka.veglib = c->d_veglib; ka.cell_params = c->d_cp; ka.hpi = c->d_hpi; ka.hpd = c->d_hpd;
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
+  ka.glist = nullptr; ka.gcount = c->nhru;
   ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.hstate = c->d_hstate; ka.list = nullptr; ka.count = nullptr;
   ka.phase = 0;
-  CArgs ca;
-  ca.ncell = c->ncell; ca.nhru = c->nhru; ca.cell_off = c->d_cell_off; ca.cell_list = c->d_cell_list; ca.hpd = c->d_hpd;
+  CArgs& ca = plan.ca;
+  ca.ncell = c->ncell; ca.nhru = c->nhru; ca.c0 = 0; ca.ccount = c->ncell;
+  ca.cell_off = c->d_cell_off; ca.cell_list = c->d_cell_list; ca.hpd = c->d_hpd;
   ca.hpi_glac = c->d_hpi + (size_t)HPI_IS_GLACIER * c->nhru;
   ca.flux = c->d_flux; ca.sd = c->d_sd; ca.hru_err = c->d_hru_err; ca.cell_out = c->d_cell_out; ca.accum = c->d_accum;
   ca.cell_err = c->d_cell_err;
-  for (int s = step0; s < step0 + nsteps; s++) {
-    ka.forcing = c->d_forcing + (size_t)s * VIC_NFORCE * nsub * c->ncell;
-    ka.snowflag = c->d_snowflag + (size_t)s * nsub * c->ncell;
-    const int* d = &c->dmy[(size_t)s * VIC_NDMY];
-    ka.dmy.month = d[VIC_DMY_MONTH]; ka.dmy.day_in_year = d[VIC_DMY_DAY_IN_YEAR]; ka.dmy.hour = d[VIC_DMY_HOUR];
-    ka.dmy.day = d[VIC_DMY_DAY]; ka.dmy.year = d[VIC_DMY_YEAR];
-    HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0)], c->stream));
-    hipError_t e;
-    if (!c->fd) {
-      e = launch_hru<3>(ka, c->stream, true, c->any_glacier);      // QUICK_FLUX implies Nnode == 3 (vicgpu_create)
-      HIPCHK(c, e);
-    } else {
-      const int r = fd_step(c, ka);
-      if (r != VICGPU_OK) return r;
+  if (!c->fd) {
+    // QUICK_FLUX (implies Nnode == 3, vicgpu_create): one kernel per step, enqueued without blocking
+    for (int s = step0; s < step0 + nsteps; s++) {
+      set_step_inputs(c, ka, s);
+      HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0)], c->stream));
+      HIPCHK(c, launch_hru<3>(ka, c->stream, true, c->any_glacier));
+      HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0) + 1], c->stream));
+      hipLaunchKernelGGL(vic_cell_reduce, dim3((c->ncell + 255) / 256), dim3(256), 0, c->stream, ca);
+      HIPCHK(c, hipGetLastError());
+      c->steps_done++;
     }
-    HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0) + 1], c->stream));
-    hipLaunchKernelGGL(vic_cell_reduce, dim3((c->ncell + 255) / 256), dim3(256), 0, c->stream, ca);
-    HIPCHK(c, hipGetLastError());
-    c->steps_done++;
+    c->ev_used = nsteps;
+    c->ev_steps = nsteps;
+    return VICGPU_OK;
   }
-  c->ev_used = nsteps;
+  // finite-difference pipeline: every chunk runs all nsteps on its own stream (ordered after what is queued on the
+  // context's stream, which in turn waits for every chunk before anything queued later)
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  for (FdChunk& ch : c->chunks) {
+    HIPCHK(c, hipStreamWaitEvent(ch.stream, c->ev[0], 0));
+    ch.status = VICGPU_OK;
+    ch.err.clear();
+  }
+  if (c->chunks.size() == 1) c->chunks[0].status = fd_chunk_run(plan, &c->chunks[0]);
+  else {
+    std::vector<std::thread> th;
+    for (FdChunk& ch : c->chunks) th.emplace_back([&plan, &ch]() { ch.status = fd_chunk_run(plan, &ch); });
+    for (std::thread& t : th) t.join();
+  }
+  int status = VICGPU_OK;
+  for (FdChunk& ch : c->chunks) {
+    if (ch.status != VICGPU_OK && status == VICGPU_OK) { status = ch.status; c->err = ch.err; }
+  }
+  if (status != VICGPU_OK) {
+    for (FdChunk& ch : c->chunks) HIPIGN(hipStreamSynchronize(ch.stream));
+    return status;
+  }
+  for (FdChunk& ch : c->chunks) HIPCHK(c, hipStreamWaitEvent(c->stream, ch.done, 0));
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  c->ev_used = 1;
+  c->ev_steps = nsteps;
+  c->steps_done += nsteps;
   return VICGPU_OK;
 }
 
@@ -1005,8 +1157,8 @@ int vicgpu_last_kernel_ms(vicgpu_ctx* c, double* ms_per_launch, int* nlaunch) {
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]));
     tot += ms;
   }
-  *ms_per_launch = c->ev_used ? tot / c->ev_used : 0.0;
-  if (nlaunch) *nlaunch = c->ev_used;
+  *ms_per_launch = c->ev_steps ? tot / c->ev_steps : 0.0;
+  if (nlaunch) *nlaunch = c->ev_steps;
   return VICGPU_OK;
 }
 
