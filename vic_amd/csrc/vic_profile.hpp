@@ -26,15 +26,23 @@ namespace vic {
 struct PArgs {
   const double* __restrict__ pin;    // item blocks [nhru][Nn][PREC]
   const double* __restrict__ ts;     // trial surface temperature [nhru]
-  double* __restrict__ pout;         // [nhru][pout_stride(Nn)]: T[Nn], {fbmask | ok << 32}, int fallback counts [Nn]
+  double* __restrict__ pout;         // [nhru][pout_hru_stride(Nn)]: two solution records + the trial temperature of each
+  const int* __restrict__ pslot;     // [nhru] record the next solve of this HRU is written to
   const int* __restrict__ list;      // HRUs to solve
   const int* __restrict__ count;     // number of list entries
   int* next;                         // work-list cursor (zero at launch; the evaluation kernel clears it again)
   int* count_zero;                   // counter of the list the following evaluation kernel appends to (cleared here)
+  int* evalonly_zero;                // counter of HRUs whose next evaluation needs no solve (cleared here)
   int Nn, NOFLUX, EXP_TRANS, TFALLBACK;
 };
 
+// One solution record: T[Nn], {fbmask | ok << 32}, int fallback counts [Nn].  Every HRU keeps the records of its last
+// two solves together with the trial temperatures they belong to: the Brent iteration on Tsurf ends with one more
+// evaluation AT the root, which is one of the last two trial points unless the solver fell back -- the same inputs give
+// the same profile bit for bit, so that solve is looked up instead of repeated (vic_surf_eval).
 __host__ __device__ inline int pout_stride(int Nn) { return Nn + 1 + (Nn + 1) / 2; }
+__host__ __device__ inline int pout_hru_stride(int Nn) { return 2 * pout_stride(Nn) + 2; }
+__host__ __device__ inline int pout_key(int Nn, int slot) { return 2 * pout_stride(Nn) + slot; }
 
 constexpr int PROFILE_GATE = 16;     // lanes that must be waiting before the write-back / fetch section runs
 
@@ -44,7 +52,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   __shared__ double T0l[NN * 64];     // previous step    [node][lane]
   const int lane = threadIdx.x;
   const int n = *a.count;
-  if (blockIdx.x == 0 && lane == 0) *a.count_zero = 0;
+  if (blockIdx.x == 0 && lane == 0) { *a.count_zero = 0; *a.evalonly_zero = 0; }
   if ((int)blockIdx.x * 64 >= n) return;           // more waves than work: nothing to pull
 
   const int Nn = (NN == VIC_MAX_NODES) ? a.Nn : NN;
@@ -63,6 +71,8 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   double maxdiff = threshold, oldT = 0;
   const double* __restrict__ blk = a.pin;
   int* __restrict__ outc = nullptr;
+  double* __restrict__ out = a.pout;
+  double* __restrict__ key = a.pout;
   Brent br;
   SoilThermalEqn eq;
   br.phase = Brent::DONE;
@@ -94,11 +104,11 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
               fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
             } else ok = false;
           }
-          double* __restrict__ out = a.pout + (size_t)hru * pout_stride(Nn);
 #pragma unroll
           for (int k = 0; k < NN; k++)
             if (k < Nn) out[k] = TL(k);
           out[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
+          *key = T0L(0);                   // the trial surface temperature this record belongs to
         }
         // next item: one atomic for all waiting lanes
         const int leader = __ffsll((long long)waiting) - 1;
@@ -109,7 +119,13 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         if (slot < n) {
           hru = a.list[slot];
           blk = a.pin + (size_t)hru * Nn * PREC;
-          outc = reinterpret_cast<int*>(a.pout + (size_t)hru * pout_stride(Nn) + Nn + 1);
+          {
+            const int ps = a.pslot[hru];
+            double* __restrict__ rec = a.pout + (size_t)hru * pout_hru_stride(Nn);
+            out = rec + ps * pout_stride(Nn);
+            outc = reinterpret_cast<int*>(out + Nn + 1);
+            key = rec + pout_key(Nn, ps);
+          }
           frozen_on = blk[PR_A] != 0.0;
           const double Ts = a.ts[hru];
 #pragma unroll

@@ -228,10 +228,13 @@ struct SurfSolve {
   Brent br;
   double x, Tsurf, snow_surf_temp, Ts_old, error;
   int stage, fbflag, fbcount, ok;
+  int final_slot, on_record;   // finite-difference pipeline: the profile record of the final evaluation's solve, and
+                               // whether that solve is already on record (no profile solve before the final evaluation)
 };
 
 VIC_DEV void surf_solve_begin(const Opt& o, SurfSolve& sv, double T0, double Tair, bool INCLUDE_SNOW, double snow_surf_temp) {
   sv.Ts_old = T0; sv.snow_surf_temp = snow_surf_temp; sv.fbflag = 0; sv.fbcount = 0; sv.ok = 1; sv.error = 0; sv.Tsurf = 0;
+  sv.final_slot = 0; sv.on_record = 0;
   if (o.FULL_ENERGY) {
     double T_lower, T_upper;
     if (INCLUDE_SNOW) { T_lower = T0 - SURF_DT; T_upper = 0.; }

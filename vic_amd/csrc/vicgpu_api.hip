@@ -56,7 +56,8 @@ struct KArgs {
   unsigned long long* ctx;          // parked per-HRU context, [hru / 64][word][hru % 64]
   double* pin;                      // profile item blocks [nhru][Nn][PREC]
   double* ts;                       // trial surface temperature [nhru]
-  const double* pout;               // profile solutions [nhru][pout_stride(Nn)]
+  double* pout;                     // profile solutions [nhru][pout_hru_stride(Nn)] (two records + their keys)
+  int* pslot;                       // [nhru] record the next profile solve writes
   int* hstate;                      // [nhru] 0 idle, 1 residual evaluation pending, 2 root found: stage kernel's turn
   int* list;                        // work list the stage kernel appends to
   int* count;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     PROF_ADD(11, t_stage);
     PROF_T0(t_post);
     // the soil profile of the final evaluation
-    const double* __restrict__ po = a.pout + (size_t)g * pout_stride(Nn);
+    const double* __restrict__ po = a.pout + (size_t)g * pout_hru_stride(Nn) + sv.final_slot * pout_stride(Nn);
     const int* __restrict__ poc = reinterpret_cast<const int*>(po + Nn + 1);
     double Tprof[NN];
     int cntprof[NN];
@@ -518,6 +519,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     PROF_T0(t_put);
     profile_item_store<NN>(o, cv, s3, w.nd, eb.delta_t, eb.frozen_on != 0, a.pin + (size_t)g * Nn * PREC);
     a.ts[g] = sv.x;
+    a.pslot[g] = 0;
+    a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 0)] = NAN;      // no solve on record yet
+    a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 1)] = NAN;
     ctx_put(cx, CO_SV, sv);
     ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
     ctx_put(cx, CO_EBC, static_cast<const SurfEBConst&>(eb));
@@ -553,11 +557,13 @@ struct EArgs {
   unsigned long long* ctx;
   size_t ctx_words;
   const double* pout;
+  int* pslot;
   double* ts;
   int* hstate;
   int* list_next;
   int* count_next;
   int* profile_next;     // work-list cursor of the profile kernel, cleared for its next launch
+  int* evalonly;         // HRUs that wait for an evaluation without a solve (final evaluation on record)
 };
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vic_surf_eval(const EArgs a) {
@@ -576,16 +582,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   ctx_get(cx, CO_SV, sv);
   ctx_get(cx, CO_EBM, static_cast<SurfEBMut&>(eb));
   ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
-  const double* __restrict__ po = a.pout + (size_t)g * pout_stride(a.Nn);
+  const double* __restrict__ rec = a.pout + (size_t)g * pout_hru_stride(a.Nn);
+  // the record the profile kernel has just written, or the one found on record for the final evaluation
+  const int slot = sv.on_record ? sv.final_slot : a.pslot[g];
+  const double* __restrict__ po = rec + slot * pout_stride(a.Nn);
   const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
+  if (sv.stage == SurfSolve::FINAL) sv.final_slot = slot;
   const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
   surf_solve_consume(a.o, sv, eb, fx);
+  bool need_solve = sv.stage != SurfSolve::DONE;
+  if (sv.stage == SurfSolve::FINAL) {
+    // the root has been found: the final evaluation needs the profile at sv.x, which is on record if sv.x is one of the
+    // last two trial points; the evaluation itself happens in the next round, together with everybody else's
+    if (rec[pout_key(a.Nn, slot)] == sv.x) { sv.final_slot = slot; sv.on_record = 1; need_solve = false; }
+    else if (rec[pout_key(a.Nn, slot ^ 1)] == sv.x) { sv.final_slot = slot ^ 1; sv.on_record = 1; need_solve = false; }
+  }
   ctx_put(cx, CO_SV, sv);
   ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
-  const bool pend = sv.stage != SurfSolve::DONE;
-  if (pend) a.ts[g] = sv.x;
-  else a.hstate[g] = 2;
-  list_append(a.list_next, a.count_next, pend, g);
+  if (sv.stage == SurfSolve::DONE) a.hstate[g] = 2;
+  else if (need_solve) { a.ts[g] = sv.x; a.pslot[g] = slot ^ 1; }     // keep the record just used, overwrite the older one
+  list_append(a.list_next, a.count_next, need_solve, g);
+  {
+    const unsigned long long m = __ballot(sv.stage != SurfSolve::DONE && !need_solve);
+    if (m != 0 && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(a.evalonly, __popcll(m));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ cell kernel
@@ -655,7 +675,7 @@ struct FdChunk {
   int* d_glist = nullptr;          // their HRUs, ascending
   int gcount = 0;
   int* d_list[2] = {nullptr, nullptr};   // work lists (HRU ids)
-  int* d_count = nullptr;          // [0..1] list sizes, [2] profile-kernel cursor
+  int* d_count = nullptr;          // [0..1] list sizes, [2] profile-kernel cursor, [3] evaluation-only HRUs
   int* h_count = nullptr;          // pinned read-back
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
@@ -689,7 +709,7 @@ struct vicgpu_ctx {
   bool fd = false;
   unsigned long long* d_ctx = nullptr;
   double *d_pin = nullptr, *d_ts = nullptr, *d_pout = nullptr;
-  int* d_hstate = nullptr;
+  int *d_hstate = nullptr, *d_pslot = nullptr;
   int profile_waves = 0;           // resident waves of the profile kernel
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
@@ -697,7 +717,7 @@ struct vicgpu_ctx {
 
 static void free_domain(vicgpu_ctx* c) {
   void* ps[] = {c->d_cp, c->d_hpd, c->d_sd, c->d_flux, c->d_cell_out, c->d_accum, c->d_hpi, c->d_si, c->d_cell_off, c->d_cell_list,
-                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate};
+                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_pslot};
   for (void* p : ps) HIPIGN(hipFree(p));
   for (FdChunk& ch : c->chunks) {
     HIPIGN(hipFree(ch.d_glist)); HIPIGN(hipFree(ch.d_list[0])); HIPIGN(hipFree(ch.d_list[1])); HIPIGN(hipFree(ch.d_count));
@@ -706,7 +726,7 @@ static void free_domain(vicgpu_ctx* c) {
     if (ch.stream) HIPIGN(hipStreamDestroy(ch.stream));
   }
   c->chunks.clear();
-  c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = nullptr;
+  c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = c->d_pslot = nullptr;
   c->d_cp = c->d_hpd = c->d_sd = c->d_flux = c->d_cell_out = c->d_accum = nullptr;
   c->d_hpi = c->d_si = c->d_cell_off = c->d_cell_list = c->d_hru_err = c->d_cell_err = nullptr;
 }
@@ -729,6 +749,7 @@ template <int NN>
 static hipError_t launch_profile(const PArgs& pa, int nmax, int resident_waves, hipStream_t st) {
   int nblk = (nmax + 63) / 64;
   if (nblk > resident_waves) nblk = resident_waves;      // persistent waves pull from the work list
+  if (nblk < 1) nblk = 1;                                // block 0 also clears the counters of the round
   hipLaunchKernelGGL((vic_profile_solve<NN>), dim3(nblk), dim3(64), 0, st, pa);
   return hipGetLastError();
 }
@@ -753,10 +774,11 @@ static int profile_resident_waves(int device) {
 // One model step of the finite-difference pipeline for one chunk (see the header of this file).  Blocks the calling
 // host thread: the number of Brent rounds is data dependent, so the pending count is read back once the first rounds
 // are through.
-static int fd_read_count(FdChunk* ch, int which, int* out) {
-  CHKCH(ch, hipMemcpyAsync(ch->h_count, ch->d_count + which, sizeof(int), hipMemcpyDeviceToHost, ch->stream));
+static int fd_read_count(FdChunk* ch, int which, int* nsolve, int* nevalonly) {
+  CHKCH(ch, hipMemcpyAsync(ch->h_count, ch->d_count, sizeof(int) * 4, hipMemcpyDeviceToHost, ch->stream));
   CHKCH(ch, hipStreamSynchronize(ch->stream));
-  *out = ch->h_count[0];
+  *nsolve = ch->h_count[which];
+  *nevalonly = ch->h_count[3];
   return VICGPU_OK;
 }
 
@@ -770,19 +792,19 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur;
   CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st)));
   PArgs pa;
-  pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
+  pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.pslot = c->d_pslot; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
   pa.TFALLBACK = c->o.TFALLBACK; pa.next = ch->d_count + 2;
   EArgs ea;
   ea.o = c->o; ea.ncell = c->ncell; ea.nhru = c->nhru; ea.Nn = Nn; ea.glist = ch->d_glist; ea.gcount = ch->gcount;
   ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
   ea.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
-  ea.pout = c->d_pout; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + 2;
+  ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + 2; ea.evalonly = ch->d_count + 3;
   const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
     int nmax = ch->gcount;
     for (int round = 0;; round++) {
-      pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur; pa.count_zero = ch->d_count + (cur ^ 1);
+      pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur; pa.count_zero = ch->d_count + (cur ^ 1); pa.evalonly_zero = ch->d_count + 3;
       CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, st) : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, st)));
       ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1);
       hipLaunchKernelGGL(vic_surf_eval, dim3((ch->gcount + 63) / 64), dim3(64), 0, st, ea);
@@ -790,18 +812,18 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
       cur ^= 1;
       ch->rounds++;
       if (round + 1 >= FREE_ROUNDS) {
-        int n = 0;
-        const int r = fd_read_count(ch, cur, &n);
+        int n = 0, ne = 0;
+        const int r = fd_read_count(ch, cur, &n, &ne);
         if (r != VICGPU_OK) return r;
-        if (n == 0) break;
+        if (n == 0 && ne == 0) break;
         nmax = n;
       }
     }
     ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur;
     CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st)));
     if (p < nsub) {
-      int n = 0;
-      const int r = fd_read_count(ch, cur, &n);
+      int n = 0, ne = 0;
+      const int r = fd_read_count(ch, cur, &n, &ne);
       if (r != VICGPU_OK) return r;
       if (n == 0) break;
     }
@@ -985,11 +1007,13 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
     HIPCHK(c, hipMalloc(&c->d_ctx, sizeof(unsigned long long) * words * (((size_t)nhru + 63) / 64 * 64)));
     HIPCHK(c, hipMalloc(&c->d_pin, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, hipMalloc(&c->d_ts, sizeof(double) * nhru));
-    HIPCHK(c, hipMalloc(&c->d_pout, sizeof(double) * (size_t)pout_stride(Nn) * nhru));
+    HIPCHK(c, hipMalloc(&c->d_pout, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
+    HIPCHK(c, hipMalloc(&c->d_pslot, sizeof(int) * nhru));
+    HIPCHK(c, hipMemset(c->d_pslot, 0, sizeof(int) * nhru));
     HIPCHK(c, hipMalloc(&c->d_hstate, sizeof(int) * nhru));
     HIPCHK(c, hipMemset(c->d_hstate, 0, sizeof(int) * nhru));
     HIPCHK(c, hipMemset(c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
-    HIPCHK(c, hipMemset(c->d_pout, 0, sizeof(double) * (size_t)pout_stride(Nn) * nhru));
+    HIPCHK(c, hipMemset(c->d_pout, 0, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
     c->profile_waves = (Nn == 10) ? profile_resident_waves<10>(c->device) : profile_resident_waves<VIC_MAX_NODES>(c->device);
     // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  One chunk is the
     // default: the persistent profile kernel fills every SIMD, so concurrent chunks mostly queue behind each other.
@@ -1011,7 +1035,7 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
       HIPCHK(c, hipMalloc(&ch.d_list[0], gb));
       HIPCHK(c, hipMalloc(&ch.d_list[1], gb));
       HIPCHK(c, hipMalloc(&ch.d_count, sizeof(int) * 4));
-      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * 2, hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * 4, hipHostMallocDefault));
       if (ch.gcount) HIPCHK(c, hipMemcpy(ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
       HIPCHK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
       HIPCHK(c, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
@@ -1087,7 +1111,7 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   ka.veglib = c->d_veglib; ka.cell_params = c->d_cp; ka.hpi = c->d_hpi; ka.hpd = c->d_hpd;
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
   ka.glist = nullptr; ka.gcount = c->nhru;
-  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.hstate = c->d_hstate; ka.list = nullptr; ka.count = nullptr;
+  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.pslot = c->d_pslot; ka.hstate = c->d_hstate; ka.list = nullptr; ka.count = nullptr;
   ka.phase = 0;
   CArgs& ca = plan.ca;
   ca.ncell = c->ncell; ca.nhru = c->nhru; ca.c0 = 0; ca.ccount = c->ncell;
