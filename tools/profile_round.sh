@@ -1,0 +1,12 @@
+# Round profile of the default bench workload (run on the GPU box: gpurun -- 'bash tools/profile_round.sh').
+# 1) kernel trace + stats of `bench.py` (the command the bench line comes from), 2) HBM traffic: FETCH_SIZE and
+# WRITE_SIZE in separate PMC passes (they do not fit one pass on gfx950).  Output under gpurun_out/round/.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/round
+rm -rf $O && mkdir -p $O
+ARGS=${BENCH_ARGS:---steps 6 --warmup 2 --no-cpu-baseline}
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 $R/bench.py $ARGS > $O/bench_trace.log 2>&1 || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $R/bench.py $ARGS > $O/bench_fetch.log 2>&1 || exit 1
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python3 $R/bench.py $ARGS > $O/bench_write.log 2>&1 || exit 1
+echo ok

@@ -33,9 +33,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise VicGpuError("HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+    path = os.environ.get("VICGPU_LIB", LIB_PATH)      # tuning: an alternative build of the same library (tools/ab.sh)
+    if not os.path.exists(path):
+        raise VicGpuError("HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+    lib = ctypes.CDLL(path)
     vp = ctypes.c_void_p
     sig = {
         "vicgpu_abi_version": (ctypes.c_int, []),

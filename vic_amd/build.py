@@ -20,10 +20,10 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, extra=(), verbose=False):
-    if not force and not needs_build():
+def build(force=False, extra=(), verbose=False, out=OUT):
+    if not force and out == OUT and not needs_build():
         return OUT
-    cmd = [HIPCC] + FLAGS + list(extra) + [SRC, "-o", OUT]
+    cmd = [HIPCC] + FLAGS + list(extra) + [SRC, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -31,5 +31,10 @@ def build(force=False, extra=(), verbose=False):
 
 
 if __name__ == "__main__":
-    extra = [a for a in sys.argv[1:] if a != "-f"]
-    build(force="-f" in sys.argv, extra=extra, verbose=True)
+    args = [a for a in sys.argv[1:] if a != "-f"]
+    out = OUT
+    if "-o" in args:                       # tuning variant: python vic_amd/build.py -f -o vic_amd/libvicgpu_b.so -DX
+        i = args.index("-o")
+        out = os.path.abspath(args[i + 1])
+        del args[i:i + 2]
+    build(force="-f" in sys.argv, extra=args, verbose=True, out=out)

@@ -364,13 +364,13 @@ VIC_DEV bool surface_fluxes_glac(const Opt& o, const CellView& cv, const VegLib&
 
     double stability_factor[2], ra_s[NPET], ra_o[NPET], pe[NPET];
     if (ra_used[0] == HUGE_RESIST) stability_factor[0] = HUGE_RESIST;
-    else stability_factor[0] = ra_used[0] / Ra.v[UnderStory];
+    else stability_factor[0] = ra_used[0] / vsel(Ra, UnderStory);
     if (ra_used[1] == ra_used[0]) stability_factor[1] = stability_factor[0];
     else if (ra_used[1] == HUGE_RESIST) stability_factor[1] = HUGE_RESIST;
     else stability_factor[1] = ra_used[1] / Ra.v[CANOPY];
 #pragma unroll
     for (int p = 0; p < NPET; p++) {
-      ra_s[p] = (stability_factor[0] == HUGE_RESIST) ? HUGE_RESIST : aero_pet[p].v[UnderStory] * stability_factor[0];
+      ra_s[p] = (stability_factor[0] == HUGE_RESIST) ? HUGE_RESIST : vsel(aero_pet[p], UnderStory) * stability_factor[0];
       ra_o[p] = (stability_factor[1] == HUGE_RESIST) ? HUGE_RESIST : aero_pet[p].v[CANOPY] * stability_factor[1];
     }
     compute_pot_evap(o, vl, veg_idx, dmy.month, fc.v(VIC_F_SHORTWAVE, hidx), NetLongAtmos_sticky, Tair, VPDcanopy, cv.s(CP_ELEVATION),

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         eq.A = A; eq.B = B; eq.C = C; eq.D = D; eq.E = r[PR_E];
         eq.max_moist = r[PR_MAXM]; eq.bubble = r[PR_BUB]; eq.expt = r[PR_EXPT];
         eq.EXP_TRANS = a.EXP_TRANS; eq.node = j;
+        eq.prepare();
         br.start(T0j - SOIL_DT, T0j + SOIL_DT);
         mode = BRENT;
       }

@@ -31,9 +31,10 @@ VIC_DEV void distribute_node_moisture_properties(const Opt& o, const CellView& c
   for (int n = 0; n < NN; n++) {
     if (n < Nn) {
       double z = cv.node(CPN_ZSUM, n), mmn = cv.node(CPN_MAX_MOIST, n);
-      double dl = s3.depth[l];
-      if (z == Lsum + dl && n != 0 && l != 2) nd.moist[n] = (moist[l] / dl + moist[l + 1] / s3.depth[l + 1]) / 1000 / 2.;
-      else nd.moist[n] = moist[l] / dl / 1000;
+      // l is a run-time layer index: select instead of indexing (a dynamic index would pin s3 / the HRU struct to memory)
+      double dl = sel3(s3.depth, l);
+      if (z == Lsum + dl && n != 0 && l != 2) nd.moist[n] = (sel3(moist, l) / dl + sel3(moist, l + 1) / sel3(s3.depth, l + 1)) / 1000 / 2.;
+      else nd.moist[n] = sel3(moist, l) / dl / 1000;
       if (nd.moist[n] - mmn > 0) nd.moist[n] = mmn;
       double bd = cv.lay(CPL_BULK_DENSITY, l), sd = cv.lay(CPL_SOIL_DENSITY, l), org = cv.lay(CPL_ORGANIC, l);
       double sdm = cv.lay(CPL_SOIL_DENS_MIN, l), bdm = cv.lay(CPL_BULK_DENS_MIN, l), qz = cv.lay(CPL_QUARTZ, l);
@@ -61,35 +62,44 @@ template <int NN>
 VIC_DEV bool estimate_layer_ice_content(const Opt& o, const CellView& cv, const Soil3& s3, const double* T,
                                         const double* moist, double* layer_ice, double* layer_T) {
   const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
-  double Lsum[4], Z[NN];
+  // everything the layer / node walk indexes at run time is copied into small local arrays first: dynamic indexing
+  // through the argument pointers would pin the caller's whole HRU struct to scratch memory
+  double Lsum[4], Z[NN], Tl[NN], ml[3], mml[3], dl[3], bubl[3], exl[3], outI[3], outT[3];
   Lsum[0] = 0;
 #pragma unroll
   for (int l = 1; l <= 3; l++) Lsum[l] = s3.depth[l - 1] + Lsum[l - 1];
 #pragma unroll
-  for (int n = 0; n < NN; n++) Z[n] = (n < Nn) ? cv.node(CPN_ZSUM, n) : 0.0;
+  for (int n = 0; n < NN; n++) { Z[n] = (n < Nn) ? cv.node(CPN_ZSUM, n) : 0.0; Tl[n] = T[n]; }
+#pragma unroll
+  for (int l = 0; l < 3; l++) {
+    ml[l] = moist[l]; mml[l] = s3.max_moist[l]; dl[l] = s3.depth[l]; bubl[l] = cv.lay(CPL_BUBBLE, l); exl[l] = cv.lay(CPL_EXPT, l);
+    outI[l] = 0; outT[l] = 0;
+  }
   const bool fs = o.FROZEN_SOIL && (cv.s(CP_FS_ACTIVE) != 0.0);
+  int lfail = 3;
+#pragma unroll 1
   for (int l = 0; l < 3; l++) {
     double accT = 0., accI = 0.;
     int min_n = Nn - 2;
     while (Lsum[l] < Z[min_n] && min_n > 0) min_n--;
     int max_n = 1;
     while (max_n < Nn && Lsum[l + 1] > Z[max_n]) max_n++;
-    if (max_n >= Nn) return false;
-    const double mm = s3.max_moist[l], bub = cv.lay(CPL_BUBBLE, l), ex = cv.lay(CPL_EXPT, l);
+    if (max_n >= Nn) { lfail = l; break; }      // the failing layer keeps the zeros of :512-519, later layers are not touched
+    const double mm = mml[l], bub = bubl[l], ex = exl[l];
     // walk the bracketing nodes once, carrying (z, T, ice) of the previous point: the trapezoid sums of :591-600
     double pz = 0, pT = 0, pI = 0;
     for (int n = min_n; n <= max_n; n++) {
       double tz, tT;
       if (n == min_n) {
-        tT = (Z[min_n] < Lsum[l]) ? linear_interp(Lsum[l], Z[min_n], Z[min_n + 1], T[min_n], T[min_n + 1]) : T[min_n];
+        tT = (Z[min_n] < Lsum[l]) ? linear_interp(Lsum[l], Z[min_n], Z[min_n + 1], Tl[min_n], Tl[min_n + 1]) : Tl[min_n];
         tz = Lsum[l];
       } else if (n == max_n) {
-        tT = (Z[max_n] > Lsum[l + 1]) ? linear_interp(Lsum[l + 1], Z[max_n - 1], Z[max_n], T[max_n - 1], T[max_n]) : T[max_n];
+        tT = (Z[max_n] > Lsum[l + 1]) ? linear_interp(Lsum[l + 1], Z[max_n - 1], Z[max_n], Tl[max_n - 1], Tl[max_n]) : Tl[max_n];
         tz = Lsum[l + 1];
-      } else { tT = T[n]; tz = Z[n]; }
+      } else { tT = Tl[n]; tz = Z[n]; }
       double tI = 0;
       if (fs) {
-        tI = moist[l] - maximum_unfrozen_water(tT, mm, bub, ex);
+        tI = ml[l] - maximum_unfrozen_water(tT, mm, bub, ex);
         if (tI < 0) tI = 0.;
       }
       if (n > min_n) {
@@ -98,10 +108,13 @@ VIC_DEV bool estimate_layer_ice_content(const Opt& o, const CellView& cv, const 
       }
       pz = tz; pT = tT; pI = tI;
     }
-    layer_ice[l] = accI / s3.depth[l];
-    layer_T[l] = accT / s3.depth[l];
+    outI[l] = accI / dl[l];
+    outT[l] = accT / dl[l];
   }
-  return true;
+#pragma unroll
+  for (int l = 0; l < 3; l++)
+    if (l <= lfail) { layer_ice[l] = outI[l]; layer_T[l] = outT[l]; }
+  return lfail == 3;
 }
 
 // estimate_layer_ice_content_quick_flux (soil_conduction.c:617-723)
@@ -180,7 +193,10 @@ VIC_DEV Zwt wrap_compute_zwt(const CellView& cv, const Soil3& s3, const double* 
   if (isnan(lz[2])) lz[2] = -total_depth * 100;
   int l = 2;
   double tmp_depth = total_depth;
-  while (l >= 0 && s3.max_moist[l] - moist[l] <= SMALL) { tmp_depth -= s3.depth[l]; l--; }
+  // while (l >= 0 && max_moist[l] - moist[l] <= SMALL) { tmp_depth -= depth[l]; l--; } with static indices
+#pragma unroll
+  for (int k = 2; k >= 0; k--)
+    if (l == k && s3.max_moist[k] - moist[k] <= SMALL) { tmp_depth -= s3.depth[k]; l--; }
   if (l < 0) r.zwt = 0;
   else if (l < 2) {
     double z = (l == 0) ? lz[0] : lz[1];

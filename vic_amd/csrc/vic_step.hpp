@@ -326,13 +326,13 @@ VIC_DEV void sf_sub_post(const Opt& o, const CellView& cv, const VegLib& vl, con
   // potential evaporation, surface_fluxes.c:658-693
   double stability_factor[2], ra_s[NPET], ra_o[NPET], pe[NPET];
   if (ra_used[0] == HUGE_RESIST) stability_factor[0] = HUGE_RESIST;
-  else stability_factor[0] = ra_used[0] / C.Ra.v[UnderStory];
+  else stability_factor[0] = ra_used[0] / vsel(C.Ra, UnderStory);
   if (ra_used[1] == ra_used[0]) stability_factor[1] = stability_factor[0];
   else if (ra_used[1] == HUGE_RESIST) stability_factor[1] = HUGE_RESIST;
   else stability_factor[1] = ra_used[1] / C.Ra.v[CANOPY];
 #pragma unroll
   for (int p = 0; p < NPET; p++) {
-    ra_s[p] = (stability_factor[0] == HUGE_RESIST) ? HUGE_RESIST : C.aero_pet[p].v[UnderStory] * stability_factor[0];
+    ra_s[p] = (stability_factor[0] == HUGE_RESIST) ? HUGE_RESIST : vsel(C.aero_pet[p], UnderStory) * stability_factor[0];
     ra_o[p] = (stability_factor[1] == HUGE_RESIST) ? HUGE_RESIST : C.aero_pet[p].v[CANOPY] * stability_factor[1];
   }
   PROF_T0(t_pe);

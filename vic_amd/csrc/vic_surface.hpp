@@ -14,30 +14,44 @@ VIC_DEV double estimate_T1(double Ts, double T1_old, double T2, double D1, doubl
          / (C1 / delta_t + kappa2 / D1 / D2 * C2 + C3 / 2. / D2);
 }
 
-// residual of one frozen node (soil_thermal_eqn.c:8-131)
+// residual of one frozen node (soil_thermal_eqn.c:8-131).  prepare() hoists what does not depend on the trial
+// temperature out of the Brent iteration (same operations, same bits): the divisor and exponent of the
+// freezing-point-depression curve (maximum_unfrozen_water), B*(TL-TU) and the |TL-TU| > 5 test of the node-1 special case.
 struct SoilThermalEqn {
   double TL, TU, T0, moist, max_moist, bubble, expt, ice0, A, B, C, D, E;
-  int EXP_TRANS, node;
+  double den, yexp, flux_term1;
+  int EXP_TRANS, node, steep;
+  VIC_DEV void prepare() {
+    den = 9.81 * bubble / 100.;
+    yexp = -(2.0 / (expt - 3.0));
+    flux_term1 = B * (TL - TU);
+    steep = (node == 1 && fabs(TL - TU) > 5.) ? 1 : 0;
+  }
   VIC_DEV double operator()(double T) const {
     double ice;
     if (T < 0.) {
-      ice = moist - maximum_unfrozen_water(T, max_moist, bubble, expt);
+      double u = max_moist * pow_pos((-LF * T) / 273.16 / den, yexp);       // maximum_unfrozen_water, T <= 0 branch
+      if (u > max_moist) u = max_moist;
+      if (u < 0) u = 0;
+      ice = moist - u;
       if (ice < 0.) ice = 0.;
       if (ice > max_moist) ice = max_moist;
     } else ice = 0.;
-    double value, flux_term1, flux_term2;
+    double value;
     if (!EXP_TRANS) {
-      value = -A * (T - T0) + B * (TL - TU) + C * (TL - T) - D * (T - TU) + E * (ice - ice0);
-      flux_term1 = B * (TL - TU);
-      flux_term2 = C * (TL - T) - D * (T - TU);
-      if (node == 1 && fabs(TL - TU) > 5. && (T < TL && T < TU) && (flux_term1 < 0 && flux_term2 > 0) && fabs(flux_term1) > fabs(flux_term2))
-        value = -A * (T - T0) + C * (TL - T) - D * (T - TU) + E * (ice - ice0);
+      value = -A * (T - T0) + flux_term1 + C * (TL - T) - D * (T - TU) + E * (ice - ice0);
+      if (steep) {
+        const double flux_term2 = C * (TL - T) - D * (T - TU);
+        if ((T < TL && T < TU) && (flux_term1 < 0 && flux_term2 > 0) && fabs(flux_term1) > fabs(flux_term2))
+          value = -A * (T - T0) + C * (TL - T) - D * (T - TU) + E * (ice - ice0);
+      }
     } else {
-      value = -A * (T - T0) + B * (TL - TU) + C * (TL - 2. * T + TU) - D * (TL - TU) + E * (ice - ice0);
-      flux_term1 = B * (TL - TU);
-      flux_term2 = C * (TL - 2. * T + TU) - D * (TL - TU);
-      if (node == 1 && fabs(TL - TU) > 5. && (T < TL && T < TU) && (flux_term1 < 0 && flux_term2 > 0) && fabs(flux_term1) > fabs(flux_term2))
-        value = -A * (T - T0) + C * (TL - 2. * T + TU) - D * (TL - TU) + E * (ice - ice0);
+      value = -A * (T - T0) + flux_term1 + C * (TL - 2. * T + TU) - D * (TL - TU) + E * (ice - ice0);
+      if (steep) {
+        const double flux_term2 = C * (TL - 2. * T + TU) - D * (TL - TU);
+        if ((T < TL && T < TU) && (flux_term1 < 0 && flux_term2 > 0) && fabs(flux_term1) > fabs(flux_term2))
+          value = -A * (T - T0) + C * (TL - 2. * T + TU) - D * (TL - TU) + E * (ice - ice0);
+      }
     }
     return value;
   }
@@ -313,8 +327,8 @@ VIC_DEV void surf_setup(const Opt& o, const CellView& cv, const VegLib& vl, cons
   eb.Wdew = vv.Wdew; eb.rainfall = rainfall; eb.Le = Le; eb.Advection = e.advection; eb.OldTSurf = OldTSurf;
   eb.kappa_snow = kappa_snow; eb.melt_energy = melt_energy; eb.snow_coverage = snow_coverage; eb.snow_density = snow.density;
   eb.snow_swq = snow.swq; eb.snow_water = snow.surf_water;
-  eb.U_under = U.v[UnderStory]; eb.zref_under = zref.v[UnderStory]; eb.disp_under = disp.v[UnderStory];
-  eb.z0_under = z0.v[UnderStory]; eb.ra_under = Ra.v[UnderStory];
+  eb.U_under = vsel(U, UnderStory); eb.zref_under = vsel(zref, UnderStory); eb.disp_under = vsel(disp, UnderStory);
+  eb.z0_under = z0.v[UnderStory]; eb.ra_under = vsel(Ra, UnderStory);
 #pragma unroll
   for (int l = 0; l < 3; l++) { eb.lmoist[l] = lmoist[l]; eb.lice[l] = lice[l]; eb.root[l] = root[l]; eb.layerevap[l] = layerevap[l]; }
   eb.Tsnow_surf = snow.surf_temp;

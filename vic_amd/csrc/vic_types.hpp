@@ -12,7 +12,7 @@
 #include "vicgpu.h"
 
 #define VIC_DEV __device__ __forceinline__
-#define VIC_DEVN __device__ __noinline__
+#define VIC_DEVN __device__ __forceinline__
 
 namespace vic {
 
@@ -129,6 +129,11 @@ struct Soil3 {
 };
 
 struct Vc { double v[NCASE]; };
+// v[k] for a run-time k without indexing memory: a dynamically indexed member would pin the whole enclosing struct
+// (HruWork, StepConst, ...) to scratch memory instead of registers
+VIC_DEV double sel_by_value(double a, double b, double c, double d, int k) { return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d)); }
+VIC_DEV double sel3(const double* a, int k) { return sel_by_value(a[0], a[1], a[2], a[2], k); }
+VIC_DEV double vsel(const Vc& x, int k) { return sel_by_value(x.v[0], x.v[1], x.v[2], x.v[3], k); }
 
 // ---- per-HRU working state ----
 struct Snow {

@@ -330,8 +330,9 @@ VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView&
   top_layer_thermal_properties(cv, s3, w.moist, w.ice, w.so.kappa, w.so.Cs);
   C.bare_albedo = GLAC ? cv.s(CP_GLAC_ALBEDO) : vl.f(veg_idx, VL_ALBEDO + month - 1);
 
-  // aerodynamic resistances for the 6 PET surfaces and the current vegetation (full_energy.c:302-354)
-  Vc& Ra = C.Ra; Vc& U = C.U; Vc& disp = C.disp; Vc& zref = C.zref; Vc& z0 = C.z0;
+  // aerodynamic resistances for the 6 PET surfaces and the current vegetation (full_energy.c:302-354).  The loop is
+  // kept rolled (7 x CalcAerodynamic); what it indexes by p lives in locals, not in C (see vsel()).
+  Vc Ra, U, disp, zref, z0, ap[NPET];
 #pragma unroll
   for (int k = 0; k < NCASE; k++) { disp.v[k] = NAN; zref.v[k] = NAN; z0.v[k] = NAN; U.v[k] = NAN; Ra.v[k] = NAN; }
   bool overstory = false;
@@ -355,11 +356,11 @@ VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView&
     if (!calc_aerodynamic(overstory, height, vl.f(pet_idx, VL_TRUNK_RATIO), snow_rough, rough, vl.f(pet_idx, VL_WIND_ATTEN), Ra, U,
                           disp, zref, z0))
       err |= VICGPU_CELLERR_AERO;
-    if (p < NPET) {
-#pragma unroll
-      for (int k = 0; k < NCASE; k++) C.aero_pet[p].v[k] = Ra.v[k];
-    }
+    if (p < NPET) ap[p] = Ra;
   }
+#pragma unroll
+  for (int p = 0; p < NPET; p++) C.aero_pet[p] = ap[p];
+  C.Ra = Ra; C.U = U; C.disp = disp; C.zref = zref; C.z0 = z0;
   C.overstory = overstory ? 1 : 0;
   w.aero_resist_surface = Ra.v[SNOW_FREE];
   w.aero_resist_overstory = Ra.v[CANOPY];
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
 // HRUs whose ground-surface root of sub-step p - 1 has been found.  Either way an HRU leaves with its next sub-step
 // set up and parked (appended to the work list) or with its step finished and stored.
 template <int NN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void vic_fd_stage(const KArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vic_fd_stage(const KArgs a) {
   const int gi = blockIdx.x * 64 + threadIdx.x;
   if (gi >= a.gcount) return;
   const int g = a.glist ? a.glist[gi] : gi;
