@@ -58,10 +58,9 @@ def cpu_baseline(cfg, target_seconds=15.0):
     opt = cfg["opt"]
     variant = "plain" if not opt.FROZEN_SOIL else ("compat" if opt.frozen_compat else "fixed")
     kind = "reference" if pyref.have_ref(variant) else "port"
-    ncell_s, nsteps = 256, 8
-    for attempt in range(2):
-        o2 = copy.copy(opt)
-        d = domain.make_domain(ncell_s, o2, ntile=cfg["ntile"])
+
+    def run(ncell_s, nsteps):
+        d = domain.make_domain(ncell_s, copy.copy(opt), ntile=cfg["ntile"])
         f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=cfg["start_doy"])
         sd0, si0 = init_state.initial_state(d, f[0])
         m = pyref.RefModel(d, variant) if kind == "reference" else pyref.OracleModel(d)
@@ -69,15 +68,32 @@ def cpu_baseline(cfg, target_seconds=15.0):
         m.set_state(sd0, si0)
         secs = m.run(f, sf, dmy, nthreads)
         m.close()
-        rate = ncell_s * nsteps / secs
-        if attempt == 0:
-            # size the real sample for ~target_seconds of CPU work
-            want = max(1.0, target_seconds * rate)
-            nsteps = 24
-            ncell_s = int(min(cfg["ncell"], max(256, want / nsteps)))
+        return secs, nthreads
+
+    # calibrate on a sample big enough to give every core work, then size the timed sample for ~target_seconds
+    ncell_s, nsteps = 2048, 4
+    secs, nthreads = run(ncell_s, nsteps)
+    rate = ncell_s * nsteps / secs
+    nsteps = 12
+    ncell_s = int(min(cfg["ncell"], max(2048, target_seconds * rate / nsteps)))
+    secs, nthreads = run(ncell_s, nsteps)
+    rate = ncell_s * nsteps / secs
     return {"value": rate, "unit": "cell-timesteps/s", "cores": nthreads, "kind": kind,
             "sample": "%d cells x %d steps of the same workload (%.1f s, OpenMP over cells, %s)" % (
                 ncell_s, nsteps, secs, "reference build oracle/_ref/libvicref_%s.so" % variant if kind == "reference" else "oracle/libvicoracle.so")}
+
+
+def measured_traffic(config_name, ncell):
+    """HBM bytes per step from the committed PMC passes of this workload (profiles/r01_traffic.json, written by
+    tools/round_summary.py from separate FETCH_SIZE / WRITE_SIZE passes); None when no measurement matches."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    if t.get("config") != config_name or t.get("cells_per_gpu") != ncell:
+        return None
+    return t.get("hbm_bytes_per_step")
 
 
 def main():
@@ -160,11 +176,16 @@ def main():
                        "cells_with_error_flags": nerr,
                        "mean_runoff_mm_per_step": float(acc[C["CA_RUNOFF"]].mean() / max(1, K)),
                        "mean_swe_mm_end": float(acc[C["CA_SWE_END"]].mean())},
+            # one "launch" of the hot path = one model step of the rank's cells: the QUICK_FLUX path is a single kernel, the
+            # finite-difference path a pipeline of kernels (stage / profile solve / surface evaluation); the duration is
+            # measured with HIP events on the library's streams around the whole step
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "vic_hru_step", "kernel_ms_per_launch": kernel_ms, "launches_timed": nlaunch,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, ncell),
+                         "kernel": "vic_hru_step" if opt.QUICK_FLUX else "vic_fd_stage + vic_profile_solve + vic_surf_eval (per-step pipeline)",
+                         "kernel_ms_per_launch": kernel_ms, "launches_timed": nlaunch,
                          "algorithmic_bytes_per_cell_step": balg,
-                         "note": "fp64 VALU/transcendental/divergence-bound path (SURVEY.md 7.3 #4): HBM fraction is small by construction"},
+                         "note": "fp64 VALU / divergence-bound root finding (SURVEY.md 7.3 #4): the algorithmic HBM fraction is small by construction; "
+                                 "profiles/ holds the per-kernel rocprofv3 stats and PMC passes"},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
