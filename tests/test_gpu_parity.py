@@ -184,3 +184,65 @@ def test_chunking_is_invisible(monkeypatch):
         del m
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def _cfg3(ncell, nsteps):
+    """The bench workload (bench.py cfg3 = BASELINE.json configs[2]): FULL_ENERGY + FROZEN_SOIL, 10 nodes, 5 bands x 5 tiles."""
+    import bench
+    cfg = bench.config("cfg3")
+    d = domain.make_domain(ncell, cfg["opt"], ntile=cfg["ntile"])
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=cfg["start_doy"])
+    sd0, si0 = init_state.initial_state(d, f[0])
+    return d, f, sf, dmy, sd0, si0
+
+
+def test_bench_workload_against_oracle(oracle_lib):
+    """cfg3 exactly as bench.py builds it, at a size the oracle finishes in seconds, free-running for a day."""
+    from vic_amd.api import Model
+    nsteps = 24
+    d, f, sf, dmy, sd0, si0 = _cfg3(48, nsteps)
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    gpu = Model(d)
+    gpu.set_state(sd0, si0)
+    gpu.push_forcing(f, sf, dmy)
+    gpu.dist_prec(0, nsteps)
+    for s in range(nsteps):
+        orc.step(f[s], sf[s], dmy[s])
+    so, _ = orc.get_state()
+    sg, _ = gpu.get_state()
+    assert gpu.get_cell_errors().sum() == 0
+    so[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
+    w, m = worst(so, sg, "SD_", floor=1e-6)
+    assert w < FREE_TOL, m
+
+
+def test_bench_workload_full_size_properties():
+    """BASELINE size (100k cells x 25 HRUs = 2.5 M HRUs), size-independent properties of the GPU path:
+    water balance closes per cell, no cell raises an error flag, and a second run from the same state is bit-identical
+    (the work lists of the kernel pipeline are filled in a scheduling-dependent order that must not matter)."""
+    from vic_amd.api import Model
+    nsteps = 3
+    d, f, sf, dmy, sd0, si0 = _cfg3(100000, nsteps)
+    cv = d.hru_dparams[C["HPD_CV"]]; cell = d.hru_iparams[C["HPI_CELL"]]
+
+    def storage(sd):
+        s = sd[C["SD_MOIST0"]] + sd[C["SD_MOIST1"]] + sd[C["SD_MOIST2"]] + sd[C["SD_WDEW"]] \
+            + (sd[C["SD_SNOW_SWQ"]] + sd[C["SD_SNOW_CANOPY"]]) * 1000.
+        return np.bincount(cell, weights=s * cv, minlength=d.ncell)
+    gpu = Model(d)
+    runs = []
+    for rep in range(2):
+        gpu.set_state(sd0, si0)
+        gpu.reset_accum()
+        gpu.push_forcing(f, sf, dmy)
+        gpu.dist_prec(0, nsteps)
+        sd1, si1 = gpu.get_state()
+        runs.append((sd1, si1, gpu.get_accum()))
+    assert gpu.get_cell_errors().sum() == 0
+    sd1, si1, acc = runs[0]
+    resid = (storage(sd1) - storage(sd0)) - (acc[C["CA_PREC"]] - acc[C["CA_EVAP"]] - acc[C["CA_RUNOFF"]] - acc[C["CA_BASEFLOW"]])
+    assert np.abs(resid).max() < 1e-6, np.abs(resid).max()
+    assert np.isfinite(sd1[C["SD_MOIST0"]]).all()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b, equal_nan=True)

@@ -44,7 +44,10 @@ __host__ __device__ inline int pout_stride(int Nn) { return Nn + 1 + (Nn + 1) / 
 __host__ __device__ inline int pout_hru_stride(int Nn) { return 2 * pout_stride(Nn) + 2; }
 __host__ __device__ inline int pout_key(int Nn, int slot) { return 2 * pout_stride(Nn) + slot; }
 
-constexpr int PROFILE_GATE = 16;     // lanes that must be waiting before the write-back / fetch section runs
+#ifndef PROFILE_GATE_LANES
+#define PROFILE_GATE_LANES 16
+#endif
+constexpr int PROFILE_GATE = PROFILE_GATE_LANES;     // lanes that must be waiting before the write-back / fetch section runs
 
 template <int NN>
 __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
