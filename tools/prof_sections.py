@@ -13,12 +13,12 @@ sys.path.insert(0, ROOT)
 CYC = {0: "stage / monolithic kernel total", 1: "load + prepare + aero", 2: "solve_snow", 3: "root finder (monolithic)",
        5: "compute_pot_evap", 6: "runoff", 7: "zwt + distribute_node_moisture", 8: "store", 9: "  snow_intercept (in 2)",
        10: "  snow_melt (in 2)", 11: "context get", 12: "sf_sub_post", 13: "sf_sub_pre (incl. solve_snow)", 14: "item block + context put",
-       15: "sf_end (incl. runoff, zwt)"}
+       15: "sf_end (incl. runoff, zwt)",
+       20: "profile kernel: gate (write-back + fetch)", 21: "profile kernel: node entry / closed form", 22: "profile kernel: frozen-node residual",
+       23: "profile kernel: Brent step", 24: "profile kernel: node finish + loop"}
 CNT = {0: "waves (stage launches)", 1: "lanes", 2: "sub-steps (wave)",
        7: "SurfEB evals (wave)", 8: "SurfEB evals (lane)", 9: "SnowPackEB evals (wave)", 10: "SnowPackEB evals (lane)",
-       11: "CanopyEB evals (wave)", 12: "CanopyEB evals (lane)",
-       20: "profile kernel: wave trips", 21: "  lanes waiting at the gate", 22: "  lanes entering a node", 23: "  lanes in a Brent solve",
-       24: "  lanes idle (list exhausted)", 25: "  Brent lanes in the main iteration", 26: "gate openings", 27: "  lanes served per opening"}
+       11: "CanopyEB evals (wave)", 12: "CanopyEB evals (lane)"}
 
 
 def main():

@@ -197,6 +197,71 @@ struct Brent {
   }
 };
 
+// root_brent for a residual that never returns the -999 error sentinel (the frozen-node residual, soil_thermal_eqn.c,
+// has no error return): the bisection searches toward a valid side (root_brent.c:129-177, 192-238) are unreachable, so
+// the state is a, b, c, d, e, fa, fb, fc and three counters, and one step is branch-light.  Where the reference would
+// misread a residual of exactly -999.0 as an error flag this treats it as the number it is.  Same operations otherwise.
+struct BrentLean {
+  enum Phase : int { EVAL_A0, EVAL_B0, EXP_A, EXP_B, MAIN, DONE };
+  double a, b, c, d, e, fa, fb, fc, x, result;
+  int phase, i, j;
+  VIC_DEV void start(double lower, double upper) {
+    a = lower; b = upper; c = 0; d = 0; e = 0; fa = fb = fc = 0;
+    i = j = 0; result = ERROR_VAL;
+    phase = EVAL_A0; x = a;
+  }
+  VIC_DEV void fail() { result = ERROR_VAL; phase = DONE; }
+  VIC_DEV void advance(double fx) {
+    if (phase == EVAL_A0 || phase == EXP_A) {              // residual at the lower end, next: the upper end
+      fa = fx; x = b;
+      phase = (phase == EVAL_A0) ? (int)EVAL_B0 : (int)EXP_B;
+      return;
+    }
+    fb = fx;
+    if (phase == MAIN) {                                   // root_brent.c:323-332
+      i++;
+      if (i >= Brent::MAXITER) { fail(); return; }
+    } else {                                               // both ends evaluated: bracket test, root_brent.c:183-248
+      j = (phase == EVAL_B0) ? 0 : j + 1;
+      if ((fa * fb) >= 0) {
+        if (j < Brent::MAXTRIES) { a -= Brent::TSTEP; b += Brent::TSTEP; phase = EXP_A; x = a; }
+        else fail();
+        return;
+      }
+      fc = fb; i = 0;
+    }
+    // main-loop body, root_brent.c:258-322 (see Brent::main_prestep)
+    const bool c1 = fb * fc > 0;
+    const double ba = b - a;
+    c = c1 ? a : c; fc = c1 ? fa : fc; d = c1 ? ba : d; e = c1 ? ba : e;
+    const bool c2 = fabs(fc) < fabs(fb);
+    {
+      const double oa = a, ob = b, oc = c, ofa = fa, ofb = fb, ofc = fc;
+      a = c2 ? ob : oa; b = c2 ? oc : ob; c = c2 ? ob : oc;
+      fa = c2 ? ofb : ofa; fb = c2 ? ofc : ofb; fc = c2 ? ofb : ofc;
+    }
+    const double tol = 2 * Brent::MACHEPS * fabs(b) + Brent::TTOL;
+    const double m = 0.5 * (c - b);
+    if (fabs(m) <= tol || fb == 0) { result = b; phase = DONE; return; }
+    const bool bisect = fabs(e) < tol || fabs(fa) <= fabs(fb);
+    const double s = fb / fa, q1 = fa / fc, r = fb / fc;
+    const bool secant = (a == c);
+    double p = secant ? 2 * m * s : s * (2 * m * q1 * (q1 - r) - (b - a) * (r - 1));
+    double q = secant ? 1 - s : (q1 - 1) * (r - 1) * (s - 1);
+    const bool ppos = p > 0;
+    q = ppos ? -q : q;
+    p = ppos ? p : -p;
+    const double s2 = e;
+    const bool accept = !bisect && (2 * p) < (3 * m * q - fabs(tol * q)) && p < fabs(0.5 * s2 * q);
+    const double pq = p / q;
+    e = accept ? d : m;
+    d = accept ? pq : m;
+    a = b; fa = fb;
+    b += (fabs(d) > tol) ? d : ((m > 0) ? tol : -tol);
+    phase = MAIN; x = b;
+  }
+};
+
 template <class F>
 VIC_DEV double root_brent(double lower, double upper, F& f) {
   Brent st;

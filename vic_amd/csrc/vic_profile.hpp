@@ -76,17 +76,23 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   int* __restrict__ outc = nullptr;
   double* __restrict__ out = a.pout;
   double* __restrict__ key = a.pout;
-  Brent br;
+  BrentLean br;
   SoilThermalEqn eq;
-  br.phase = Brent::DONE;
+  br.phase = BrentLean::DONE;
+#ifdef VIC_PROF
+  long long tp_gate = 0, tp_node = 0, tp_eq = 0, tp_adv = 0, tp_done = 0, tp_last = (long long)__builtin_readcyclecounter();
+#define TP(acc) do { const long long n_ = (long long)__builtin_readcyclecounter(); acc += n_ - tp_last; tp_last = n_; } while (0)
+#else
+#define TP(acc) do { } while (0)
+#endif
 
   while (true) {
+    TP(tp_done);
     // ---- gate: write-back of finished solves + fetch of new items (wave-uniform branch)
     const unsigned long long waiting = __ballot(mode == FINISH);
     const unsigned long long running = __ballot(mode == NODE || mode == BRENT);
     if (waiting == 0 && running == 0) break;             // every lane is IDLE
     if (waiting != 0 && (__popcll(waiting) >= PROFILE_GATE || running == 0)) {
-      PROF_WAVE(26); PROF_VOTE(27, mode == FINISH);
       if (mode == FINISH) {
         if (hru >= 0) {
           if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T[j]); Tlast == T0
@@ -140,9 +146,8 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         } else { hru = -1; mode = IDLE; }
       }
     }
+    TP(tp_gate);
     // ---- one unit of work per lane
-    PROF_WAVE(20); PROF_VOTE(21, mode == FINISH); PROF_VOTE(22, mode == NODE); PROF_VOTE(23, mode == BRENT); PROF_VOTE(24, mode == IDLE);
-    PROF_VOTE(25, mode == BRENT && br.phase == Brent::MAIN);
     bool node_done = false;
     double newT = 0;
     if (mode == NODE) {
@@ -166,10 +171,12 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         mode = BRENT;
       }
     }
+    TP(tp_node);
     if (mode == BRENT) {
       const double fx = eq(br.x);
+      TP(tp_eq);
       br.advance(fx);
-      if (br.phase == Brent::DONE) {
+      if (br.phase == BrentLean::DONE) {
         double rt = br.result;
         if (is_error(rt)) {
           if (a.TFALLBACK) { rt = eq.T0; fbmask |= (1u << j); CNT(j) += 1; }
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         if (mode == BRENT) { newT = rt; node_done = true; mode = NODE; }
       }
     }
+    TP(tp_adv);
     if (node_done) {
       TL(j) = newT;
       const double diff = fabs(oldT - newT);
@@ -190,6 +198,14 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
       }
     }
   }
+#ifdef VIC_PROF
+  if (lane == 0) {
+    atomicAdd(&vic_prof_cyc[20], (unsigned long long)tp_gate); atomicAdd(&vic_prof_cyc[21], (unsigned long long)tp_node);
+    atomicAdd(&vic_prof_cyc[22], (unsigned long long)tp_eq); atomicAdd(&vic_prof_cyc[23], (unsigned long long)tp_adv);
+    atomicAdd(&vic_prof_cyc[24], (unsigned long long)tp_done);
+  }
+#endif
+#undef TP
 #undef TL
 #undef T0L
 #undef CNT
