@@ -246,3 +246,77 @@ def test_bench_workload_full_size_properties():
     assert np.isfinite(sd1[C["SD_MOIST0"]]).all()
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("quickflux_bands", dict(FULL_ENERGY=1, Nband=3)),
+    ("frozen_fixed_bands", dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=2, frozen_compat=0)),
+])
+def test_irregular_domain(name, kw, oracle_lib):
+    """Artificial bare-soil HRUs, Cv = 0 tiles, zero-area bands, ragged HRU lists and an empty cell
+    (tests/util.py edge_domain; the oracle is bit-exact against the reference on it, tests/test_oracle.py)."""
+    from vic_amd.api import Model
+    from tests.util import edge_domain, active_hrus
+    opt = abi.default_options(**kw)
+    d = edge_domain(opt)
+    act = active_hrus(d)
+    nsteps = 48
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=75)
+    sd0, si0 = init_state.initial_state(d, f[0])
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    gpu = Model(d)
+    gpu.push_forcing(f, sf, dmy)
+    for s in range(nsteps):
+        sd_in, si_in = orc.get_state()
+        fo, co, eo = orc.step(f[s], sf[s], dmy[s])
+        so, io = orc.get_state()
+        gpu.set_state(sd_in, si_in)
+        gpu.dist_prec(s, 1)
+        sg, ig = gpu.get_state()
+        fg = gpu.get_fluxes()
+        cg = gpu.get_cell_outputs()
+        assert gpu.get_cell_errors().sum() == 0 and eo.sum() == 0
+        assert np.nanmax(np.abs(so[C["SD_ERROR"]] - sg[C["SD_ERROR"]])) < 1e-3
+        so[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
+        w1, m1 = worst(so, sg, "SD_", floor=1e-6)
+        w2, m2 = worst(fo[FLUX_ROWS_COMMON][:, act], fg[FLUX_ROWS_COMMON][:, act], "FX_", floor=1e-6)
+        w3, m3 = worst(co, cg, "CO_", floor=1e-6)
+        assert w1 < TF_TOL, "step %d state %s" % (s, m1)
+        assert w2 < TF_TOL, "step %d flux %s" % (s, m2)
+        assert w3 < TF_TOL, "step %d cell %s" % (s, m3)
+        # HRUs the step skips keep their state bit for bit
+        assert np.array_equal(sg[:, ~act], sd_in[:, ~act], equal_nan=True)
+
+
+def test_api_rejects_bad_calls():
+    """Error behaviour of the C ABI (include/vicgpu.h): wrong shapes and out-of-range requests come back as error codes,
+    never as a launch with bad indices."""
+    from vic_amd.api import Model, VicGpuError
+    import copy
+    opt = abi.default_options(FULL_ENERGY=1)
+    d = domain.make_domain(16, opt, ntile=2)
+    f, sf, dmy = domain.make_forcing(d, 0, 4, start_doy=10)
+    m = Model(d)
+    with pytest.raises(VicGpuError):
+        m.dist_prec(0, 1)                      # no forcing pushed yet
+    m.push_forcing(f, sf, dmy)
+    with pytest.raises(VicGpuError):
+        m.dist_prec(3, 2)                      # runs past the pushed chunk
+    with pytest.raises(VicGpuError):
+        m.dist_prec(-1, 1)
+    bad = dmy.copy()
+    bad[0, C["VIC_DMY_MONTH"]] = 13
+    with pytest.raises(VicGpuError):
+        m.push_forcing(f, sf, bad)             # the month indexes the vegetation library tables
+    # an HRU list that names an HRU of another cell
+    d2 = copy.copy(d)
+    d2.cell_hru_list = d.cell_hru_list.copy()
+    d2.cell_hru_list[[0, 1]] = d2.cell_hru_list[[1, 0]] if d.cell_hru_offset[1] == 1 else d2.cell_hru_list[[0, 1]]
+    d2.hru_iparams = d.hru_iparams.copy()
+    d2.hru_iparams[C["HPI_BAND"], 0] = opt.Nband          # band index out of range
+    with pytest.raises(VicGpuError):
+        Model(d2)
+    # QUICK_FLUX needs three nodes, FROZEN_SOIL excludes it (get_global_param.c:376-381,1151-1155)
+    with pytest.raises(VicGpuError):
+        Model(domain.make_domain(4, abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, QUICK_FLUX=1, Nnode=3), ntile=1))

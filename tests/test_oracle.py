@@ -75,6 +75,42 @@ def test_oracle_vs_reference_side_by_side(case, oracle_lib, ref_available):
     ref.close()
 
 
+@pytest.mark.parametrize("name,kw,variant", [
+    ("quickflux_bands", dict(FULL_ENERGY=1, Nband=3), "plain"),
+    ("frozen_fixed_bands", dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=2, frozen_compat=0), "fixed"),
+])
+def test_oracle_vs_reference_irregular_domain(name, kw, variant, oracle_lib, ref_available):
+    """Artificial bare-soil HRUs, Cv = 0 tiles, zero-area bands, ragged HRU lists and an empty cell (tests/util.py
+    edge_domain): the oracle against the real reference, bit for bit."""
+    if not ref_available:
+        pytest.skip("reference build (oracle/_ref) not available")
+    from tests.util import edge_domain, active_hrus
+    opt = abi.default_options(**kw)
+    d = edge_domain(opt)
+    act = active_hrus(d)
+    assert 0 < act.sum() < d.nhru and d.hru_iparams[C["HPI_IS_ARTIFICIAL_BARE"]].sum() > 0
+    nsteps = 96
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=75)
+    ref = oracle_lib.RefModel(d, variant)
+    ref.init_state(f[0], dmy[0], d.init_moist)
+    sd0, si0 = ref.get_state()
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    rows = [r for r in range(C["FX_NROW"]) if r not in (C["FX_OUT_PREC"], C["FX_OUT_RAIN"], C["FX_OUT_SNOW"])]
+    for s in range(nsteps):
+        fr, cr, er = ref.step(f[s], sf[s], dmy[s])
+        fo, co, eo = orc.step(f[s], sf[s], dmy[s])
+        sr, ir = ref.get_state()
+        so, io = orc.get_state()
+        assert er.sum() == 0 and eo.sum() == 0
+        assert rel_diff(sr, so, 1e-12).max() == 0.0, "step %d %s" % (s, worst(sr, so, "SD_", 1e-12)[1])
+        fra, foa = fr[rows][:, act], fo[rows][:, act]
+        assert rel_diff(fra, foa, 1e-12).max() == 0.0, "step %d %s" % (s, worst(fra, foa, "FX_", 1e-12)[1])
+        assert rel_diff(cr, co, 1e-12).max() == 0.0
+        assert np.array_equal(ir, io)
+    ref.close()
+
+
 def test_root_brent_known_cubic(oracle_lib):
     """root_brent on a known cubic: x^3 - 2x - 5 has its real root at 2.0945514815423265."""
     import ctypes

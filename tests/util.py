@@ -33,3 +33,35 @@ FLUX_ROWS_COMMON = [C[k] for k in (
     "FX_AERO_RESIST_SURFACE", "FX_AERO_RESIST_OVERSTORY", "FX_ROOTMOIST", "FX_WETNESS", "FX_ZWT", "FX_ZWT2", "FX_ZWT3",
     "FX_ATMOS_LATENT", "FX_ATMOS_LATENT_SUB", "FX_ATMOS_SENSIBLE", "FX_LONG_UNDER_IN", "FX_NET_LONG_ATMOS", "FX_NET_LONG_UNDER",
     "FX_NET_SHORT_ATMOS", "FX_NET_SHORT_GRND", "FX_NET_SHORT_UNDER", "FX_SHORT_UNDER_IN")]
+
+
+def edge_domain(opt, ncell=24, ntile=3, seed=7):
+    """A domain with the irregularities of real parameter files: an artificial bare-soil tile (read_vegparam.c:312-340),
+    vegetation tiles with Cv = 0 and snow bands with AreaFract = 0 (both skipped by full_energy.c:220-231), cells with
+    fewer HRUs than others and one cell with no HRU at all."""
+    from vic_amd import abi, domain
+    d = domain.make_domain(ncell, opt, ntile=ntile, bare_fraction=0.25, seed=seed)
+    hpd, hpi, cp = d.hru_dparams, d.hru_iparams, d.cell_params
+    cell, band = hpi[C["HPI_CELL"]], hpi[C["HPI_BAND"]]
+    slot = np.arange(d.nhru) // d.ncell
+    # Cv = 0 for the second vegetation tile of every fifth cell
+    z = (cell % 5 == 1) & (slot // opt.Nband == 1)
+    hpd[C["HPD_CV"], z] = 0.0
+    # a band without area in every fourth cell (its HRUs keep their Cv, the band test skips them)
+    if opt.Nband > 1:
+        cells = np.arange(d.ncell)
+        cp[abi.cp_band(C["CPB_AREAFRACT"], opt.Nband - 1, opt.Nnode, opt.Nband), cells % 4 == 2] = 0.0
+    # ragged lists: drop the last vegetation tile of every third cell, and every HRU of cell 5
+    drop = ((cell % 3 == 0) & (slot // opt.Nband == ntile - 1)) | (cell == 5)
+    domain.drop_hrus(d, drop)
+    return d
+
+
+def active_hrus(d):
+    """HRUs the step actually computes (full_energy.c:220-231: Cv > 0 and the band has area); the flux rows of the others
+    are not defined by either implementation (put_data never reads them)."""
+    from vic_amd import abi
+    hpd, hpi, cp, opt = d.hru_dparams, d.hru_iparams, d.cell_params, d.opt
+    cell, band = hpi[C["HPI_CELL"]], hpi[C["HPI_BAND"]]
+    area = np.array([cp[abi.cp_band(C["CPB_AREAFRACT"], b, opt.Nnode, opt.Nband), c] for b, c in zip(band, cell)])
+    return (hpd[C["HPD_CV"]] > 0) & (area > 0)

@@ -223,12 +223,16 @@ class Domain:
     pass
 
 
-def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, seed=SEED, band_spread=400.0):
+def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, seed=SEED, band_spread=400.0, bare_fraction=0.0):
     """Regular grid of `ncell` cells, opt.Nband snow bands x ntile veg tiles per band.
 
     HRU numbering is slot-major: hru = slot * ncell + cell with slot = tile * Nband + band, so a
     wavefront of consecutive HRUs covers consecutive cells of the same (tile, band) — coalesced
     forcing / parameter loads and a uniform vegetation class per wavefront.
+
+    bare_fraction > 0 leaves that fraction of every cell without vegetation, which read_vegparam.c:312-340 fills with one
+    "artificial" bare-soil HRU per band (vegIndex = num_veg_types, Cv = (1 - Cv_sum) / Nband, no root zones); those HRUs
+    take the last slots.
     """
     rng = np.random.default_rng(seed)
     Nn, Nb = opt.Nnode, opt.Nband
@@ -334,13 +338,14 @@ def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, 
     if tile_classes is None:
         tile_classes = [0, 1, 0, 1, 0][:ntile] if ntile > 1 else [0]
     assert len(tile_classes) == ntile
-    nslot = ntile * Nb
+    nbare = 1 if bare_fraction > 0 else 0
+    nslot = (ntile + nbare) * Nb
     nhru = nslot * ncell
     d.nhru = nhru
     d.nslot = nslot
     hpi = np.zeros((C["HPI_NROW"], nhru), dtype=np.int32)
     hpd = np.zeros((C["HPD_NROW"], nhru))
-    tile_frac = np.full(ntile, 1.0 / ntile)
+    tile_frac = np.full(ntile, (1.0 - bare_fraction) / ntile)
     roots = {0: (0.10, 0.70, 0.20), 1: (0.10, 0.60, 0.30), 2: (0.0, 0.0, 0.0)}
     cells = np.arange(ncell)
     for k in range(ntile):
@@ -360,6 +365,16 @@ def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, 
             r = roots[vidx]
             for l in range(3):
                 hpd[C["HPD_ROOT0"] + l, g] = np.float32(r[l])
+    if nbare:
+        for b in range(Nb):
+            g = (ntile * Nb + b) * ncell + cells
+            hpi[C["HPI_CELL"], g] = cells
+            hpi[C["HPI_BAND"], g] = b
+            hpi[C["HPI_VEG_INDEX"], g] = nveg                  # veg_lib[num_veg_types]: the first appended PET surface
+            hpi[C["HPI_VEG_CLASS"], g] = nveg
+            hpi[C["HPI_IS_GLACIER"], g] = 0
+            hpi[C["HPI_IS_ARTIFICIAL_BARE"], g] = 1
+            hpd[C["HPD_CV"], g] = bare_fraction / Nb
     d.hru_iparams = np.ascontiguousarray(hpi)
     d.hru_dparams = np.ascontiguousarray(hpd)
     d.cell_hru_offset = np.ascontiguousarray((np.arange(ncell + 1) * nslot).astype(np.int32))
@@ -368,6 +383,28 @@ def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, 
     d.cell_offset_T = rng.uniform(-3, 3, ncell)
     d.rng_seed = seed
     return d
+
+
+def drop_hrus(d, drop):
+    """Removes the HRUs flagged in the boolean array `drop` (a cell may end up with fewer HRUs than its neighbours, or
+    none): ragged cell -> HRU lists as real vegetation parameter files produce them.  Returns the kept HRU indices."""
+    keep = np.flatnonzero(~np.asarray(drop, dtype=bool))
+    newid = -np.ones(d.nhru, dtype=np.int64)
+    newid[keep] = np.arange(keep.size)
+    d.hru_iparams = np.ascontiguousarray(d.hru_iparams[:, keep])
+    d.hru_dparams = np.ascontiguousarray(d.hru_dparams[:, keep])
+    off = [0]
+    lst = []
+    for c in range(d.ncell):
+        g = d.cell_hru_list[d.cell_hru_offset[c]:d.cell_hru_offset[c + 1]]
+        g = newid[g]
+        g = g[g >= 0]
+        lst.append(g)
+        off.append(off[-1] + g.size)
+    d.cell_hru_offset = np.ascontiguousarray(np.array(off, dtype=np.int32))
+    d.cell_hru_list = np.ascontiguousarray(np.concatenate(lst).astype(np.int32)) if keep.size else np.zeros(0, np.int32)
+    d.nhru = int(keep.size)
+    return keep
 
 
 def svp(T):
