@@ -16,6 +16,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -858,10 +859,18 @@ static int fd_chunk_run(const StepPlan& plan, FdChunk* ch) {
   CArgs ca = plan.ca;
   ka.glist = ch->d_glist; ka.gcount = ch->gcount;
   ca.c0 = ch->c0; ca.ccount = ch->ccount;
+  const bool trace = getenv("VICGPU_TRACE") != nullptr;      // tuning: per-step wall time and Brent rounds (adds a sync per step)
   for (int s = plan.step0; s < plan.step0 + plan.nsteps; s++) {
     set_step_inputs(c, ka, s);
+    const long long r0 = ch->rounds;
+    const auto t0 = std::chrono::steady_clock::now();
     const int r = fd_step(c, ch, ka);
     if (r != VICGPU_OK) return r;
+    if (trace) {
+      CHKCH(ch, hipStreamSynchronize(ch->stream));
+      fprintf(stderr, "[vicgpu] step %d hour %d: %.2f ms, %lld rounds\n", s, ka.dmy.hour,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ch->rounds - r0);
+    }
     hipLaunchKernelGGL(vic_cell_reduce, dim3((ch->ccount + 255) / 256), dim3(256), 0, ch->stream, ca);
     CHKCH(ch, hipGetLastError());
   }
