@@ -70,7 +70,10 @@ struct SoilThermalEqn {
 // A-D depend only on kappa, Cs, the node geometry and dt, i.e. they are the same for every residual evaluation of one
 // Brent solve on Tsurf (upstream keeps them in static arrays for that reason; SURVEY.md Finding 1.1).
 // ------------------------------------------------------------------------------------------------
-constexpr int PREC = 12;
+#ifndef PROFILE_RECORD_DOUBLES
+#define PROFILE_RECORD_DOUBLES 12
+#endif
+constexpr int PREC = PROFILE_RECORD_DOUBLES;     // 12 used
 enum { PR_T0 = 0, PR_A, PR_B, PR_C, PR_D, PR_EI, PR_E, PR_MOIST, PR_ICE, PR_MAXM, PR_BUB, PR_EXPT };
 
 template <int NN>
