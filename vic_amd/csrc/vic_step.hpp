@@ -171,6 +171,44 @@ struct HruWork {
   double deltaCC_glac, glacier_flux, glacier_melt_energy;
 };
 
+// What of HruWork has to survive from the set-up of a sub-step (before the ground-surface root finder) to its
+// bookkeeping (after it).  Everything else is either rewritten afterwards (node temperatures come back from the profile
+// solve, node moisture / ice / conductivity from distribute_node_moisture_properties, the per-step outputs from sf_end)
+// or is unchanged state that can be re-read from the state table.
+template <int NN>
+struct WCarry {
+  double moist[3], ice[3], layer_T[3];
+  Snow snow;
+  VegVar vv;
+  SnowEnergy se;
+  SoilEnergy so;
+  double Tcanopy, aero_resist_surface, aero_resist_overstory, out_prec, out_rain, out_snow;
+  int fbcount[NN + (NN & 1)];
+};
+
+template <int NN>
+VIC_DEV void carry_out(const HruWork<NN>& w, WCarry<NN>& k) {
+#pragma unroll
+  for (int l = 0; l < 3; l++) { k.moist[l] = w.moist[l]; k.ice[l] = w.ice[l]; k.layer_T[l] = w.layer_T[l]; }
+  k.snow = w.snow; k.vv = w.vv; k.se = w.se; k.so = w.so;
+  k.Tcanopy = w.Tcanopy; k.aero_resist_surface = w.aero_resist_surface; k.aero_resist_overstory = w.aero_resist_overstory;
+  k.out_prec = w.out_prec; k.out_rain = w.out_rain; k.out_snow = w.out_snow;
+#pragma unroll
+  for (int n = 0; n < NN + (NN & 1); n++) k.fbcount[n] = (n < NN) ? w.nd.fbcount[n] : 0;
+}
+
+template <int NN>
+VIC_DEV void carry_in(const WCarry<NN>& k, HruWork<NN>& w) {
+#pragma unroll
+  for (int l = 0; l < 3; l++) { w.moist[l] = k.moist[l]; w.ice[l] = k.ice[l]; w.layer_T[l] = k.layer_T[l]; w.evap[l] = 0; }
+  w.snow = k.snow; w.vv = k.vv; w.se = k.se; w.so = k.so;
+  w.Tcanopy = k.Tcanopy; w.aero_resist_surface = k.aero_resist_surface; w.aero_resist_overstory = k.aero_resist_overstory;
+  w.out_prec = k.out_prec; w.out_rain = k.out_rain; w.out_snow = k.out_snow;
+#pragma unroll
+  for (int n = 0; n < NN; n++) { w.nd.fbcount[n] = k.fbcount[n]; w.nd.fbflag[n] = 0; w.nd.T[n] = 0; }
+}
+
+// the sub-step sums of SubLoop (all zero until the first sub-step has been booked)
 // Per-step constants of one HRU: the prologue of full_energy's HRU loop (full_energy.c:216-354)
 struct StepConst {
   Vc aero_pet[NPET];     // aero_pet[p].v = { snowFree, canopy, snowCovered, - } resistances of PET type p
@@ -198,6 +236,21 @@ struct SubLoop {
          st_throughfall, st_ppt, st_cond_surface, st_cond_overstory;
   double st_layerevap[3], st_pot_evap[NPET];
 };
+
+VIC_DEV void zero_substep_sums(SubLoop& L) {
+  L.st_AlbedoOver = 0; L.st_AlbedoUnder = 0; L.st_AtmosLatent = 0; L.st_AtmosLatentSub = 0; L.st_AtmosSensible = 0; L.st_LongOverIn = 0;
+  L.st_LongUnderIn = 0; L.st_LongUnderOut = 0; L.st_NetLongAtmos = 0; L.st_NetLongOver = 0; L.st_NetLongUnder = 0; L.st_NetShortAtmos = 0;
+  L.st_NetShortGrnd = 0; L.st_NetShortOver = 0; L.st_NetShortUnder = 0; L.st_ShortOverIn = 0; L.st_ShortUnderIn = 0;
+  L.st_advected_sensible = 0; L.st_advection = 0; L.st_canopy_advection = 0; L.st_canopy_latent = 0; L.st_canopy_latent_sub = 0;
+  L.st_canopy_sensible = 0; L.st_canopy_refreeze = 0; L.st_deltaCC = 0; L.st_deltaH = 0; L.st_fusion = 0; L.st_grnd_flux = 0;
+  L.st_latent = 0; L.st_latent_sub = 0; L.st_melt_energy = 0; L.st_refreeze_energy = 0; L.st_sensible = 0; L.st_snow_flux = 0;
+  L.st_canopy_vapor_flux = 0; L.st_melt = 0; L.st_vapor_flux = 0; L.st_blowing_flux = 0; L.st_surface_flux = 0; L.st_canopyevap = 0;
+  L.st_throughfall = 0; L.st_ppt = 0; L.st_cond_surface = 0; L.st_cond_overstory = 0;
+#pragma unroll
+  for (int l = 0; l < 3; l++) L.st_layerevap[l] = 0;
+#pragma unroll
+  for (int p = 0; p < NPET; p++) L.st_pot_evap[p] = 0;
+}
 
 struct SubStep {
   SolveSnowOut ss;
@@ -230,18 +283,7 @@ VIC_DEV void sf_begin(const Opt& o, const Forcing& fc, const StepConst& C, HruWo
   L.snow_inflow = 0;
   L.INCLUDE_SNOW = 0; L.N_steps = 0;
   L.delta_coverage = 0;
-  L.st_AlbedoOver = 0; L.st_AlbedoUnder = 0; L.st_AtmosLatent = 0; L.st_AtmosLatentSub = 0; L.st_AtmosSensible = 0; L.st_LongOverIn = 0;
-  L.st_LongUnderIn = 0; L.st_LongUnderOut = 0; L.st_NetLongAtmos = 0; L.st_NetLongOver = 0; L.st_NetLongUnder = 0; L.st_NetShortAtmos = 0;
-  L.st_NetShortGrnd = 0; L.st_NetShortOver = 0; L.st_NetShortUnder = 0; L.st_ShortOverIn = 0; L.st_ShortUnderIn = 0;
-  L.st_advected_sensible = 0; L.st_advection = 0; L.st_canopy_advection = 0; L.st_canopy_latent = 0; L.st_canopy_latent_sub = 0;
-  L.st_canopy_sensible = 0; L.st_canopy_refreeze = 0; L.st_deltaCC = 0; L.st_deltaH = 0; L.st_fusion = 0; L.st_grnd_flux = 0;
-  L.st_latent = 0; L.st_latent_sub = 0; L.st_melt_energy = 0; L.st_refreeze_energy = 0; L.st_sensible = 0; L.st_snow_flux = 0;
-  L.st_canopy_vapor_flux = 0; L.st_melt = 0; L.st_vapor_flux = 0; L.st_blowing_flux = 0; L.st_surface_flux = 0; L.st_canopyevap = 0;
-  L.st_throughfall = 0; L.st_ppt = 0; L.st_cond_surface = 0; L.st_cond_overstory = 0;
-#pragma unroll
-  for (int l = 0; l < 3; l++) L.st_layerevap[l] = 0;
-#pragma unroll
-  for (int p = 0; p < NPET; p++) L.st_pot_evap[p] = 0;
+  zero_substep_sums(L);
   w.out_prec = w.out_rain = w.out_snow = 0;
 }
 

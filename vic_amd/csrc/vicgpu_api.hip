@@ -21,6 +21,7 @@
 #include <thread>
 #include <vector>
 #include "vicgpu.h"
+#include <cstddef>
 #include <type_traits>
 #include "vic_glacier.hpp"
 #include "vic_profile.hpp"
@@ -99,7 +100,31 @@ constexpr size_t CW_SV = sizeof(SurfSolve) / 8, CW_EBM = sizeof(SurfEBMut) / 8, 
                  CW_P = sizeof(SubStep) / 8, CW_L = sizeof(SubLoop) / 8, CW_C = sizeof(StepConst) / 8;
 constexpr size_t CO_SV = 0, CO_EBM = CO_SV + CW_SV, CO_EBC = CO_EBM + CW_EBM, CO_P = CO_EBC + CW_EBC, CO_L = CO_P + CW_P,
                  CO_C = CO_L + CW_L, CO_W = CO_C + CW_C;
-template <int NN> constexpr size_t ctx_words() { return CO_W + sizeof(HruWork<NN>) / 8; }
+template <int NN> constexpr size_t ctx_words() { return CO_W + sizeof(WCarry<NN>) / 8; }
+// SubLoop in two parts: the head always, the sub-step sums only once a sub-step has been booked (they are zero before)
+constexpr size_t CW_L_HEAD = offsetof(SubLoop, st_AlbedoOver) / 8;
+
+template <class T>
+VIC_DEV void ctx_put_words(const CtxRef& r, size_t word0, const T& v, int first, int last) {
+  constexpr int NW = sizeof(T) / 8;
+  unsigned long long tmp[NW];
+  __builtin_memcpy(tmp, &v, sizeof(T));
+  unsigned long long* __restrict__ q = r.p + word0 * 64;
+#pragma unroll
+  for (int i = 0; i < NW; i++)
+    if (i >= first && i < last) q[(size_t)i * 64] = tmp[i];
+}
+template <class T>
+VIC_DEV void ctx_get_words(const CtxRef& r, size_t word0, T& v, int first, int last) {
+  constexpr int NW = sizeof(T) / 8;
+  unsigned long long tmp[NW];
+  __builtin_memcpy(tmp, &v, sizeof(T));
+  const unsigned long long* __restrict__ q = r.p + word0 * 64;
+#pragma unroll
+  for (int i = 0; i < NW; i++)
+    if (i >= first && i < last) tmp[i] = q[(size_t)i * 64];
+  __builtin_memcpy(&v, tmp, sizeof(T));
+}
 
 // wave-aggregated append of this lane's HRU to a work list (order is irrelevant: HRUs never interact)
 VIC_DEV void list_append(int* __restrict__ list, int* count, bool pred, int g) {
@@ -114,8 +139,9 @@ VIC_DEV void list_append(int* __restrict__ list, int* count, bool pred, int g) {
 }
 
 // ------------------------------------------------------------------------------------------------ state table I/O
+// node_props = false leaves the node moisture / ice / conductivity / heat-capacity rows for load_node_props
 template <int NN>
-VIC_DEV void load_state(const KArgs& a, int g, HruWork<NN>& w) {
+VIC_DEV void load_state(const KArgs& a, int g, HruWork<NN>& w, bool node_props = true) {
   const int Nn = a.o.Nnode;
   const size_t nh = a.nhru;
   const double* __restrict__ sd = a.sd;
@@ -162,9 +188,11 @@ VIC_DEV void load_state(const KArgs& a, int g, HruWork<NN>& w) {
 #pragma unroll
   for (int n = 0; n < NN; n++) {
     if (n < Nn) {
-      w.nd.T[n] = SD(VICGPU_SD_NODE(SDN_T, n, Nn)); w.nd.moist[n] = SD(VICGPU_SD_NODE(SDN_MOIST, n, Nn));
-      w.nd.ice[n] = SD(VICGPU_SD_NODE(SDN_ICE, n, Nn)); w.nd.kappa[n] = SD(VICGPU_SD_NODE(SDN_KAPPA, n, Nn));
-      w.nd.Cs[n] = SD(VICGPU_SD_NODE(SDN_CS, n, Nn));
+      w.nd.T[n] = SD(VICGPU_SD_NODE(SDN_T, n, Nn));
+      if (node_props) {
+        w.nd.moist[n] = SD(VICGPU_SD_NODE(SDN_MOIST, n, Nn)); w.nd.ice[n] = SD(VICGPU_SD_NODE(SDN_ICE, n, Nn));
+        w.nd.kappa[n] = SD(VICGPU_SD_NODE(SDN_KAPPA, n, Nn)); w.nd.Cs[n] = SD(VICGPU_SD_NODE(SDN_CS, n, Nn));
+      } else { w.nd.moist[n] = 0; w.nd.ice[n] = 0; w.nd.kappa[n] = 0; w.nd.Cs[n] = 0; }
       w.nd.fbflag[n] = SI(VICGPU_SI_NODE(SIN_T_FBFLAG, n, Nn)); w.nd.fbcount[n] = SI(VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn));
     } else {
       w.nd.T[n] = 0; w.nd.moist[n] = 0; w.nd.ice[n] = 0; w.nd.kappa[n] = 0; w.nd.Cs[n] = 0; w.nd.fbflag[n] = 0; w.nd.fbcount[n] = 0;
@@ -178,6 +206,39 @@ VIC_DEV void load_state(const KArgs& a, int g, HruWork<NN>& w) {
   w.gl.surf_temp_fbcount = SI(SI_GLAC_SURF_TEMP_FBCOUNT); w.gl.surf_temp_fbflag = SI(SI_GLAC_SURF_TEMP_FBFLAG);
 #undef SD
 #undef SI
+}
+
+// the node rows that do not change during a step (distribute_node_moisture_properties rewrites them at its end)
+template <int NN>
+VIC_DEV void load_node_props(const KArgs& a, int g, Nodes<NN>& nd) {
+  const int Nn = a.o.Nnode;
+  const size_t nh = a.nhru;
+  const double* __restrict__ sd = a.sd;
+#pragma unroll
+  for (int n = 0; n < NN; n++) {
+    if (n < Nn) {
+      nd.moist[n] = sd[(size_t)VICGPU_SD_NODE(SDN_MOIST, n, Nn) * nh + g]; nd.ice[n] = sd[(size_t)VICGPU_SD_NODE(SDN_ICE, n, Nn) * nh + g];
+      nd.kappa[n] = sd[(size_t)VICGPU_SD_NODE(SDN_KAPPA, n, Nn) * nh + g]; nd.Cs[n] = sd[(size_t)VICGPU_SD_NODE(SDN_CS, n, Nn) * nh + g];
+    }
+  }
+}
+
+// what load_state gives the fields that neither cross the root finder in the parked context nor are rewritten after it
+template <int NN>
+VIC_DEV void load_passthrough(const KArgs& a, int g, HruWork<NN>& w) {
+  const size_t nh = a.nhru;
+  const double* __restrict__ sd = a.sd;
+  const int* __restrict__ si = a.si;
+  w.gl.surf_temp = sd[(size_t)SD_GLAC_SURF_TEMP * nh + g]; w.gl.water_storage = sd[(size_t)SD_GLAC_WATER_STORAGE * nh + g];
+  w.gl.cum_mass_balance = sd[(size_t)SD_GLAC_CUM_MASS_BALANCE * nh + g];
+  w.gl.cold_content = NAN; w.gl.Qnet = NAN; w.gl.mass_balance = NAN; w.gl.ice_mass_balance = 0; w.gl.accumulation = NAN;
+  w.gl.melt = NAN; w.gl.vapor_flux = NAN; w.gl.outflow = NAN; w.gl.outflow_coef = NAN; w.gl.inflow = NAN;
+  w.gl.surf_temp_fbcount = si[(size_t)SI_GLAC_SURF_TEMP_FBCOUNT * nh + g]; w.gl.surf_temp_fbflag = si[(size_t)SI_GLAC_SURF_TEMP_FBFLAG * nh + g];
+  w.deltaCC_glac = 0; w.glacier_flux = 0; w.glacier_melt_energy = 0;
+#pragma unroll
+  for (int n = 0; n < NN; n++) { w.nd.moist[n] = 0; w.nd.ice[n] = 0; w.nd.kappa[n] = 0; w.nd.Cs[n] = 0; }
+#pragma unroll
+  for (int p = 0; p < NPET; p++) w.pot_evap[p] = 0;
 }
 
 template <int NN>
@@ -303,7 +364,7 @@ VIC_DEV Soil3 load_soil3(const CellView& cv) {
 // full_energy.c:216-354: state in, prepare_full_energy, aerodynamic resistances.  Returns the error bits.
 template <int NN, bool GLAC>
 VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView& cv, const VegLib& vl, const Forcing& fc, const Soil3& s3,
-                         HruWork<NN>& w, StepConst& C) {
+                         HruWork<NN>& w, StepConst& C, bool node_props = true) {
   const Opt& o = a.o;
   const size_t nh = a.nhru;
   const int month = a.dmy.month;
@@ -312,7 +373,7 @@ VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView&
   C.veg_idx = veg_idx; C.band = id.band; C.is_art_bare = id.is_art_bare ? 1 : 0;
 #pragma unroll
   for (int l = 0; l < 3; l++) C.root[l] = (double)(float)a.hpd[(size_t)(HPD_ROOT0 + l) * nh + g];
-  load_state<NN>(a, g, w);
+  load_state<NN>(a, g, w, node_props);
   w.snow.vapor_flux = 0.; w.snow.canopy_vapor_flux = 0.;                  // full_energy.c:261-262
 
   const double wind_h = vl.f(veg_idx, VL_WIND_H);
@@ -454,17 +515,18 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
 // Finite-difference pipeline, stage kernel: phase 0 starts the step of every ordinary HRU; phase p >= 1 resumes the
 // HRUs whose ground-surface root of sub-step p - 1 has been found.  Either way an HRU leaves with its next sub-step
 // set up and parked (appended to the work list) or with its step finished and stored.
-template <int NN>
+// FIRST: the phase-0 instantiation; MULTI: the run has more than one snow sub-step per step (otherwise phase 1 never sets up
+// another sub-step and that code is not instantiated).
+template <int NN, bool FIRST, bool MULTI>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vic_fd_stage(const KArgs a) {
   const int gi = blockIdx.x * 64 + threadIdx.x;
   if (gi >= a.gcount) return;
   const int g = a.glist ? a.glist[gi] : gi;
   const Opt& o = a.o;
-  const size_t nh = a.nhru;
   const HruId id = hru_id(a, g);
   if (id.run && id.is_glacier) return;              // vic_hru_step<NN, true> owns glacier HRUs
-  if (a.phase == 0 && !id.run) { store_zero_record(a, g); a.hstate[g] = 0; return; }
-  if (a.phase > 0 && a.hstate[g] != 2) return;
+  if (FIRST && !id.run) { store_zero_record(a, g); a.hstate[g] = 0; return; }
+  if (!FIRST && a.hstate[g] != 2) return;
   CellView cv{a.cell_params, a.ncell, id.c, o.Nnode, o.Nband};
   VegLib vl{a.veglib};
   Forcing fc{a.forcing, a.snowflag, a.ncell, id.c, o.NR + 1};
@@ -477,8 +539,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   int err = 0;
   bool more;
   PROF_T0(t_stage);
-  if (a.phase == 0) {
-    err = hru_prologue<NN, false>(a, g, id, cv, vl, fc, s3, w, C);
+  if constexpr (FIRST) {
+    err = hru_prologue<NN, false>(a, g, id, cv, vl, fc, s3, w, C, /*node_props=*/false);
     PROF_ADD(1, t_stage);
     more = !(err & VICGPU_CELLERR_AERO);
     if (more) sf_begin<NN>(o, fc, C, w, L);
@@ -486,13 +548,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     SubStep P;
     SurfEB eb;
     SurfSolve sv;
+    WCarry<NN> k;
     ctx_get(cx, CO_SV, sv);
     ctx_get(cx, CO_EBM, static_cast<SurfEBMut&>(eb));
     ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
     ctx_get(cx, CO_P, P);
-    ctx_get(cx, CO_L, L);
+    ctx_get_words(cx, CO_L, L, 0, (int)CW_L_HEAD);
+    if (MULTI && L.N_steps > 0) ctx_get_words(cx, CO_L, L, (int)CW_L_HEAD, (int)CW_L);
+    else zero_substep_sums(L);
     ctx_get(cx, CO_C, C);
-    ctx_get(cx, CO_W, w);
+    ctx_get(cx, CO_W, k);
+    carry_in<NN>(k, w);
+    load_passthrough<NN>(a, g, w);
     PROF_ADD(11, t_stage);
     PROF_T0(t_post);
     // the soil profile of the final evaluation
@@ -511,29 +578,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     more = true;
   }
   bool pend = false;
-  if (more && L.hidx < L.endhidx) {
-    SubStep P;
-    SurfEB eb;
-    SurfSolve sv;
-    PROF_T0(t_pre);
-    sf_sub_pre<NN>(o, cv, vl, s3, fc, a.dmy, C, w, L, P, eb, sv);
-    PROF_ADD(13, t_pre);
-    PROF_T0(t_put);
-    profile_item_store<NN>(o, cv, s3, w.nd, eb.delta_t, eb.frozen_on != 0, a.pin + (size_t)g * Nn * PREC);
-    a.ts[g] = sv.x;
-    a.pslot[g] = 0;
-    a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 0)] = NAN;      // no solve on record yet
-    a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 1)] = NAN;
-    ctx_put(cx, CO_SV, sv);
-    ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
-    ctx_put(cx, CO_EBC, static_cast<const SurfEBConst&>(eb));
-    ctx_put(cx, CO_P, P);
-    ctx_put(cx, CO_L, L);
-    if (a.phase == 0) ctx_put(cx, CO_C, C);
-    ctx_put(cx, CO_W, w);
-    a.hstate[g] = 1;
-    pend = true;
-    PROF_ADD(14, t_put);
+  if ((FIRST || MULTI) && more && L.hidx < L.endhidx) {
+    if constexpr (FIRST || MULTI) {
+      SubStep P;
+      SurfEB eb;
+      SurfSolve sv;
+      PROF_T0(t_pre);
+      sf_sub_pre<NN>(o, cv, vl, s3, fc, a.dmy, C, w, L, P, eb, sv);
+      PROF_ADD(13, t_pre);
+      PROF_T0(t_put);
+      ctx_put(cx, CO_SV, sv);
+      ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
+      ctx_put(cx, CO_EBC, static_cast<const SurfEBConst&>(eb));
+      ctx_put(cx, CO_P, P);
+      ctx_put_words(cx, CO_L, L, 0, (int)CW_L_HEAD);
+      if (MULTI && L.N_steps > 0) ctx_put_words(cx, CO_L, L, (int)CW_L_HEAD, (int)CW_L);
+      if (FIRST) ctx_put(cx, CO_C, C);
+      {
+        WCarry<NN> k;
+        carry_out<NN>(w, k);
+        ctx_put(cx, CO_W, k);
+      }
+      // the item block needs the node rows that nothing before it reads: loaded last, so that they are not live (and
+      // spilled) across solve_snow
+      load_node_props<NN>(a, g, w.nd);
+      profile_item_store<NN>(o, cv, s3, w.nd, eb.delta_t, eb.frozen_on != 0, a.pin + (size_t)g * Nn * PREC);
+      a.ts[g] = sv.x;
+      a.pslot[g] = 0;
+      a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 0)] = NAN;      // no solve on record yet
+      a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 1)] = NAN;
+      a.hstate[g] = 1;
+      pend = true;
+      PROF_ADD(14, t_put);
+    }
   } else {
     PROF_T0(t_end);
     if (more && !sf_end<NN>(o, cv, s3, C, w, L)) err |= VICGPU_CELLERR_SOLVER;
@@ -742,8 +819,15 @@ static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool ordinary, boo
 }
 
 template <int NN>
-static hipError_t launch_fd_stage(const KArgs& ka, hipStream_t st) {
-  hipLaunchKernelGGL((vic_fd_stage<NN>), dim3((ka.gcount + 63) / 64), dim3(64), 0, st, ka);
+static hipError_t launch_fd_stage(const KArgs& ka, bool multi, hipStream_t st) {
+  const dim3 grid((ka.gcount + 63) / 64), block(64);
+  if (ka.phase == 0) {
+    if (multi) hipLaunchKernelGGL((vic_fd_stage<NN, true, true>), grid, block, 0, st, ka);
+    else hipLaunchKernelGGL((vic_fd_stage<NN, true, false>), grid, block, 0, st, ka);
+  } else {
+    if (multi) hipLaunchKernelGGL((vic_fd_stage<NN, false, true>), grid, block, 0, st, ka);
+    else hipLaunchKernelGGL((vic_fd_stage<NN, false, false>), grid, block, 0, st, ka);
+  }
   return hipGetLastError();
 }
 
@@ -792,7 +876,7 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   CHKCH(ch, hipMemsetAsync(ch->d_count, 0, sizeof(int) * 4, st));
   int cur = 0;
   ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur;
-  CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st)));
+  CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
   PArgs pa;
   pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.pslot = c->d_pslot; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
   pa.TFALLBACK = c->o.TFALLBACK; pa.next = ch->d_count + 2;
@@ -822,7 +906,7 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
       }
     }
     ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur;
-    CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, st) : launch_fd_stage<VIC_MAX_NODES>(ka, st)));
+    CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
     if (p < nsub) {
       int n = 0, ne = 0;
       const int r = fd_read_count(ch, cur, &n, &ne);
