@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
 // FIRST: the phase-0 instantiation; MULTI: the run has more than one snow sub-step per step (otherwise phase 1 never sets up
 // another sub-step and that code is not instantiated).
 template <int NN, bool FIRST, bool MULTI>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vic_fd_stage(const KArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void vic_fd_stage(const KArgs a) {
   const int gi = blockIdx.x * 64 + threadIdx.x;
   if (gi >= a.gcount) return;
   const int g = a.glist ? a.glist[gi] : gi;
