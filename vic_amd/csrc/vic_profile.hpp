@@ -23,15 +23,22 @@
 
 namespace vic {
 
+// Work lists are kept in NBUCKET segments by a per-HRU key (the number of frozen nodes at the start of the step): the
+// profile kernel takes the segments one after the other, most expensive first, so that the HRUs a wave works on at any time
+// have the same nodes in Brent solves and need about the same number of trips -- measured on the bench workload, waves
+// of identical HRUs run the whole step 36 % faster than waves of neighbouring cells (tools/exp/homogeneous.py).
+constexpr int NBUCKET = VIC_MAX_NODES + 2;
+
 struct PArgs {
   const double* __restrict__ pin;    // item blocks [nhru][Nn][PREC]
   const double* __restrict__ ts;     // trial surface temperature [nhru]
   double* __restrict__ pout;         // [nhru][pout_hru_stride(Nn)]: two solution records + the trial temperature of each
   const int* __restrict__ pslot;     // [nhru] record the next solve of this HRU is written to
-  const int* __restrict__ list;      // HRUs to solve
-  const int* __restrict__ count;     // number of list entries
+  const int* __restrict__ list;      // HRUs to solve: NBUCKET segments of `cap` entries
+  const int* __restrict__ count;     // entries per segment [NBUCKET]
+  int cap;
   int* next;                         // work-list cursor (zero at launch; the evaluation kernel clears it again)
-  int* count_zero;                   // counter of the list the following evaluation kernel appends to (cleared here)
+  int* count_zero;                   // segment counters [NBUCKET] of the list the following evaluation kernel appends to (cleared here)
   int* evalonly_zero;                // counter of HRUs whose next evaluation needs no solve (cleared here)
   int Nn, NOFLUX, EXP_TRANS, TFALLBACK;
 };
@@ -53,10 +60,18 @@ template <int NN>
 __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   __shared__ double Tl[NN * 64];      // current iterate  [node][lane]
   __shared__ double T0l[NN * 64];     // previous step    [node][lane]
+  __shared__ int bcount[NBUCKET];
   const int lane = threadIdx.x;
-  const int n = *a.count;
-  if (blockIdx.x == 0 && lane == 0) { *a.count_zero = 0; *a.evalonly_zero = 0; }
-  if ((int)blockIdx.x * 64 >= n) return;           // more waves than work: nothing to pull
+  if (lane < NBUCKET) bcount[lane] = a.count[lane];
+  if (blockIdx.x == 0) {
+    if (lane < NBUCKET) a.count_zero[lane] = 0;
+    if (lane == 0) *a.evalonly_zero = 0;
+  }
+  __syncthreads();
+  int n = 0;
+#pragma unroll
+  for (int b = 0; b < NBUCKET; b++) n += bcount[b];
+  if ((int)blockIdx.x * 64 >= n) return;           // more waves than work: nothing to pull (the grid is sized from an upper bound)
 
   const int Nn = (NN == VIC_MAX_NODES) ? a.Nn : NN;
   const int jlast = a.NOFLUX ? Nn : Nn - 1;     // exclusive upper node of a sweep
@@ -126,7 +141,16 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         base = __builtin_amdgcn_readlane(base, leader);
         const int slot = base + __popcll(waiting & ((1ull << lane) - 1ull));
         if (slot < n) {
-          hru = a.list[slot];
+          {
+            int rem = slot, found = 0;              // segment of this slot, highest key (most work) first
+#pragma unroll 1
+            for (int b = NBUCKET - 1; b >= 0; b--) {
+              const int cb = bcount[b];
+              if (rem < cb) { found = b * a.cap + rem; break; }
+              rem -= cb;
+            }
+            hru = a.list[found];
+          }
           blk = a.pin + (size_t)hru * Nn * PREC;
           {
             const int ps = a.pslot[hru];

@@ -61,8 +61,10 @@ struct KArgs {
   double* pout;                     // profile solutions [nhru][pout_hru_stride(Nn)] (two records + their keys)
   int* pslot;                       // [nhru] record the next profile solve writes
   int* hstate;                      // [nhru] 0 idle, 1 residual evaluation pending, 2 root found: stage kernel's turn
-  int* list;                        // work list the stage kernel appends to
-  int* count;
+  int* list;                        // work list the stage kernel appends to (NBUCKET segments of list_cap entries)
+  int* count;                       // [NBUCKET]
+  int list_cap;
+  int* hkey;                        // [nhru] work-list segment of each HRU (number of frozen nodes)
   int phase;                        // 0: start of the step; p >= 1: after the root finder of sub-step p - 1
 };
 
@@ -126,16 +128,23 @@ VIC_DEV void ctx_get_words(const CtxRef& r, size_t word0, T& v, int first, int l
   __builtin_memcpy(&v, tmp, sizeof(T));
 }
 
-// wave-aggregated append of this lane's HRU to a work list (order is irrelevant: HRUs never interact)
-VIC_DEV void list_append(int* __restrict__ list, int* count, bool pred, int g) {
-  const unsigned long long m = __ballot(pred);
-  if (m == 0) return;
+// wave-aggregated append of this lane's HRU to segment `key` of a work list (order is irrelevant: HRUs never interact).
+// One atomic per distinct key, all of them in flight together: every lane finds the lanes that share its key (one
+// ballot per possible key), the first of each group reserves the group's entries.
+VIC_DEV void list_append(int* __restrict__ list, int* count, int cap, bool pred, int key, int g) {
+  if (__ballot(pred) == 0) return;
+  unsigned long long mine = 0;
+#pragma unroll 1
+  for (int k = 0; k < NBUCKET; k++) {
+    const unsigned long long m = __ballot(pred && key == k);
+    if (key == k) mine = m;
+  }
   const int lane = (int)__lane_id();
-  const int leader = __ffsll((long long)m) - 1;
+  const int rank = __popcll(mine & ((1ull << lane) - 1ull));
   int base = 0;
-  if (lane == leader) base = atomicAdd(count, __popcll(m));
-  base = __shfl(base, leader);
-  if (pred) list[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+  if (pred && rank == 0) base = atomicAdd(count + key, __popcll(mine));
+  base = __shfl(base, pred ? __ffsll((long long)mine) - 1 : lane);
+  if (pred) list[(size_t)key * cap + base + rank] = g;
 }
 
 // ------------------------------------------------------------------------------------------------ state table I/O
@@ -578,6 +587,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     more = true;
   }
   bool pend = false;
+  int key = 0;
   if ((FIRST || MULTI) && more && L.hidx < L.endhidx) {
     if constexpr (FIRST || MULTI) {
       SubStep P;
@@ -602,6 +612,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       // the item block needs the node rows that nothing before it reads: loaded last, so that they are not live (and
       // spilled) across solve_snow
       load_node_props<NN>(a, g, w.nd);
+      {
+        int nfrozen = 0;
+#pragma unroll
+        for (int n = 1; n < NN; n++)
+          if (n < Nn && eb.frozen_on && w.nd.T[n] < 0) nfrozen++;
+        key = nfrozen;
+        a.hkey[g] = key;
+      }
       profile_item_store<NN>(o, cv, s3, w.nd, eb.delta_t, eb.frozen_on != 0, a.pin + (size_t)g * Nn * PREC);
       a.ts[g] = sv.x;
       a.pslot[g] = 0;
@@ -618,7 +636,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     hru_epilogue<NN>(a, g, cv, s3, C, w, err);
     a.hstate[g] = 0;
   }
-  list_append(a.list, a.count, pend, g);
+  list_append(a.list, a.count, a.list_cap, pend, key, g);
   PROF_ADD(0, t_stage);
   PROF_WAVE(0);
   PROF_LANE(1);
@@ -639,8 +657,10 @@ struct EArgs {
   int* pslot;
   double* ts;
   int* hstate;
-  int* list_next;
-  int* count_next;
+  int* list_next;        // NBUCKET segments of list_cap entries
+  int* count_next;       // [NBUCKET]
+  int list_cap;
+  const int* hkey;
   int* profile_next;     // work-list cursor of the profile kernel, cleared for its next launch
   int* evalonly;         // HRUs that wait for an evaluation without a solve (final evaluation on record)
 };
@@ -680,7 +700,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
   if (sv.stage == SurfSolve::DONE) a.hstate[g] = 2;
   else if (need_solve) { a.ts[g] = sv.x; a.pslot[g] = slot ^ 1; }     // keep the record just used, overwrite the older one
-  list_append(a.list_next, a.count_next, need_solve, g);
+  list_append(a.list_next, a.count_next, a.list_cap, need_solve, a.hkey[g], g);
   {
     const unsigned long long m = __ballot(sv.stage != SurfSolve::DONE && !need_solve);
     if (m != 0 && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(a.evalonly, __popcll(m));
@@ -754,7 +774,8 @@ struct FdChunk {
   int* d_glist = nullptr;          // their HRUs, ascending
   int gcount = 0;
   int* d_list[2] = {nullptr, nullptr};   // work lists (HRU ids)
-  int* d_count = nullptr;          // [0..1] list sizes, [2] profile-kernel cursor, [3] evaluation-only HRUs
+  int* d_count = nullptr;          // [l * NBUCKET + b] segment sizes of list l, then CNT_CURSOR, CNT_EVALONLY
+  int list_cap = 0;                // entries per segment
   int* h_count = nullptr;          // pinned read-back
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
@@ -788,7 +809,7 @@ struct vicgpu_ctx {
   bool fd = false;
   unsigned long long* d_ctx = nullptr;
   double *d_pin = nullptr, *d_ts = nullptr, *d_pout = nullptr;
-  int *d_hstate = nullptr, *d_pslot = nullptr;
+  int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr;
   int profile_waves = 0;           // resident waves of the profile kernel
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
@@ -796,7 +817,7 @@ struct vicgpu_ctx {
 
 static void free_domain(vicgpu_ctx* c) {
   void* ps[] = {c->d_cp, c->d_hpd, c->d_sd, c->d_flux, c->d_cell_out, c->d_accum, c->d_hpi, c->d_si, c->d_cell_off, c->d_cell_list,
-                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_pslot};
+                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_pslot, c->d_hkey};
   for (void* p : ps) HIPIGN(hipFree(p));
   for (FdChunk& ch : c->chunks) {
     HIPIGN(hipFree(ch.d_glist)); HIPIGN(hipFree(ch.d_list[0])); HIPIGN(hipFree(ch.d_list[1])); HIPIGN(hipFree(ch.d_count));
@@ -805,7 +826,7 @@ static void free_domain(vicgpu_ctx* c) {
     if (ch.stream) HIPIGN(hipStreamDestroy(ch.stream));
   }
   c->chunks.clear();
-  c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = c->d_pslot = nullptr;
+  c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = c->d_pslot = c->d_hkey = nullptr;
   c->d_cp = c->d_hpd = c->d_sd = c->d_flux = c->d_cell_out = c->d_accum = nullptr;
   c->d_hpi = c->d_si = c->d_cell_off = c->d_cell_list = c->d_hru_err = c->d_cell_err = nullptr;
 }
@@ -857,14 +878,18 @@ static int profile_resident_waves(int device) {
     }                                                                                                  \
   } while (0)
 
+constexpr int CNT_CURSOR = 2 * NBUCKET, CNT_EVALONLY = 2 * NBUCKET + 1, CNT_TOTAL = 2 * NBUCKET + 2;
+
 // One model step of the finite-difference pipeline for one chunk (see the header of this file).  Blocks the calling
 // host thread: the number of Brent rounds is data dependent, so the pending count is read back once the first rounds
 // are through.
 static int fd_read_count(FdChunk* ch, int which, int* nsolve, int* nevalonly) {
-  CHKCH(ch, hipMemcpyAsync(ch->h_count, ch->d_count, sizeof(int) * 4, hipMemcpyDeviceToHost, ch->stream));
+  CHKCH(ch, hipMemcpyAsync(ch->h_count, ch->d_count, sizeof(int) * CNT_TOTAL, hipMemcpyDeviceToHost, ch->stream));
   CHKCH(ch, hipStreamSynchronize(ch->stream));
-  *nsolve = ch->h_count[which];
-  *nevalonly = ch->h_count[3];
+  int n = 0;
+  for (int b = 0; b < NBUCKET; b++) n += ch->h_count[which * NBUCKET + b];
+  *nsolve = n;
+  *nevalonly = ch->h_count[CNT_EVALONLY];
   return VICGPU_OK;
 }
 
@@ -873,26 +898,28 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   const bool n10 = (Nn == 10);
   hipStream_t st = ch->stream;
   if (c->any_glacier) CHKCH(ch, (n10 ? launch_hru<10>(ka, st, false, true) : launch_hru<VIC_MAX_NODES>(ka, st, false, true)));
-  CHKCH(ch, hipMemsetAsync(ch->d_count, 0, sizeof(int) * 4, st));
+  CHKCH(ch, hipMemsetAsync(ch->d_count, 0, sizeof(int) * CNT_TOTAL, st));
   int cur = 0;
-  ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur;
+  ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET; ka.list_cap = ch->list_cap;
   CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
   PArgs pa;
   pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.pslot = c->d_pslot; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
-  pa.TFALLBACK = c->o.TFALLBACK; pa.next = ch->d_count + 2;
+  pa.TFALLBACK = c->o.TFALLBACK; pa.next = ch->d_count + CNT_CURSOR; pa.cap = ch->list_cap;
   EArgs ea;
   ea.o = c->o; ea.ncell = c->ncell; ea.nhru = c->nhru; ea.Nn = Nn; ea.glist = ch->d_glist; ea.gcount = ch->gcount;
   ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
   ea.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
-  ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + 2; ea.evalonly = ch->d_count + 3;
+  ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + CNT_CURSOR; ea.evalonly = ch->d_count + CNT_EVALONLY;
+  ea.list_cap = ch->list_cap; ea.hkey = c->d_hkey;
   const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
     int nmax = ch->gcount;
     for (int round = 0;; round++) {
-      pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur; pa.count_zero = ch->d_count + (cur ^ 1); pa.evalonly_zero = ch->d_count + 3;
+      pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur * NBUCKET; pa.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
+      pa.evalonly_zero = ch->d_count + CNT_EVALONLY;
       CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, st) : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, st)));
-      ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1);
+      ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1) * NBUCKET;
       hipLaunchKernelGGL(vic_surf_eval, dim3((ch->gcount + 63) / 64), dim3(64), 0, st, ea);
       CHKCH(ch, hipGetLastError());
       cur ^= 1;
@@ -905,7 +932,7 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
         nmax = n;
       }
     }
-    ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur;
+    ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET;
     CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
     if (p < nsub) {
       int n = 0, ne = 0;
@@ -1103,6 +1130,8 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
     HIPCHK(c, hipMalloc(&c->d_ts, sizeof(double) * nhru));
     HIPCHK(c, hipMalloc(&c->d_pout, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
     HIPCHK(c, hipMalloc(&c->d_pslot, sizeof(int) * nhru));
+    HIPCHK(c, hipMalloc(&c->d_hkey, sizeof(int) * nhru));
+    HIPCHK(c, hipMemset(c->d_hkey, 0, sizeof(int) * nhru));
     HIPCHK(c, hipMemset(c->d_pslot, 0, sizeof(int) * nhru));
     HIPCHK(c, hipMalloc(&c->d_hstate, sizeof(int) * nhru));
     HIPCHK(c, hipMemset(c->d_hstate, 0, sizeof(int) * nhru));
@@ -1126,10 +1155,11 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
       ch.gcount = (int)gl.size();
       const size_t gb = sizeof(int) * (size_t)(ch.gcount > 0 ? ch.gcount : 1);
       HIPCHK(c, hipMalloc(&ch.d_glist, gb));
-      HIPCHK(c, hipMalloc(&ch.d_list[0], gb));
-      HIPCHK(c, hipMalloc(&ch.d_list[1], gb));
-      HIPCHK(c, hipMalloc(&ch.d_count, sizeof(int) * 4));
-      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * 4, hipHostMallocDefault));
+      ch.list_cap = ch.gcount > 0 ? ch.gcount : 1;
+      HIPCHK(c, hipMalloc(&ch.d_list[0], gb * NBUCKET));
+      HIPCHK(c, hipMalloc(&ch.d_list[1], gb * NBUCKET));
+      HIPCHK(c, hipMalloc(&ch.d_count, sizeof(int) * CNT_TOTAL));
+      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * CNT_TOTAL, hipHostMallocDefault));
       if (ch.gcount) HIPCHK(c, hipMemcpy(ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
       HIPCHK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
       HIPCHK(c, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
@@ -1205,7 +1235,7 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   ka.veglib = c->d_veglib; ka.cell_params = c->d_cp; ka.hpi = c->d_hpi; ka.hpd = c->d_hpd;
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
   ka.glist = nullptr; ka.gcount = c->nhru;
-  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.pslot = c->d_pslot; ka.hstate = c->d_hstate; ka.list = nullptr; ka.count = nullptr;
+  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.pslot = c->d_pslot; ka.hstate = c->d_hstate; ka.hkey = c->d_hkey; ka.list = nullptr; ka.count = nullptr; ka.list_cap = 0;
   ka.phase = 0;
   CArgs& ca = plan.ca;
   ca.ncell = c->ncell; ca.nhru = c->nhru; ca.c0 = 0; ca.ccount = c->ncell;
