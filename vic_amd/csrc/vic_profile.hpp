@@ -27,7 +27,10 @@ namespace vic {
 // profile kernel takes the segments one after the other, most expensive first, so that the HRUs a wave works on at any time
 // have the same nodes in Brent solves and need about the same number of trips -- measured on the bench workload, waves
 // of identical HRUs run the whole step 36 % faster than waves of neighbouring cells (tools/exp/homogeneous.py).
-constexpr int NBUCKET = VIC_MAX_NODES + 2;
+#ifndef PROFILE_NBUCKET
+#define PROFILE_NBUCKET (VIC_MAX_NODES + 2)
+#endif
+constexpr int NBUCKET = PROFILE_NBUCKET;
 
 struct PArgs {
   const double* __restrict__ pin;    // item blocks [nhru][Nn][PREC]
@@ -62,9 +65,9 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   __shared__ double T0l[NN * 64];     // previous step    [node][lane]
   __shared__ int bcount[NBUCKET];
   const int lane = threadIdx.x;
-  if (lane < NBUCKET) bcount[lane] = a.count[lane];
+  for (int b = lane; b < NBUCKET; b += 64) bcount[b] = a.count[b];
   if (blockIdx.x == 0) {
-    if (lane < NBUCKET) a.count_zero[lane] = 0;
+    for (int b = lane; b < NBUCKET; b += 64) a.count_zero[b] = 0;
     if (lane == 0) *a.evalonly_zero = 0;
   }
   __syncthreads();
