@@ -129,13 +129,15 @@ struct SurfEBConst {
   double lmoist[3], lice[3], root[3];
 };
 struct SurfEBMut {
+  // read by the next evaluation (read-modify-write, or kept when a branch does not assign them)
   double Tsnow_surf;
-  double Tnew2;                   // Tnew_node[2] of the last evaluation
   double ra_used[2];
   VegVar vv;
   double layerevap[3];
-  double deltaCC, refreeze_energy, vapor_flux, blowing_flux, surface_flux;
-  double NetLongBare, NetLongSnow, T1, deltaH, fusion, grnd_flux, latent_heat, latent_heat_sub, sensible_heat, snow_flux, error;
+  double deltaCC, refreeze_energy, vapor_flux, blowing_flux, surface_flux, NetLongSnow, fusion;
+  // assigned by every evaluation before any use: only the final evaluation's values are ever read
+  double Tnew2;                   // Tnew_node[2] of the last evaluation
+  double NetLongBare, T1, deltaH, grnd_flux, latent_heat, latent_heat_sub, sensible_heat, snow_flux, error;
 };
 
 struct SurfEB : SurfEBConst, SurfEBMut {

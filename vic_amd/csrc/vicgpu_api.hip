@@ -105,6 +105,8 @@ constexpr size_t CO_SV = 0, CO_EBM = CO_SV + CW_SV, CO_EBC = CO_EBM + CW_EBM, CO
 template <int NN> constexpr size_t ctx_words() { return CO_W + sizeof(WCarry<NN>) / 8; }
 // SubLoop in two parts: the head always, the sub-step sums only once a sub-step has been booked (they are zero before)
 constexpr size_t CW_L_HEAD = offsetof(SubLoop, st_AlbedoOver) / 8;
+// SurfEBMut: the fields an evaluation reads back, then the pure outputs (parked by the final evaluation only)
+constexpr size_t CW_EBM_FEED = offsetof(SurfEBMut, Tnew2) / 8;
 
 template <class T>
 VIC_DEV void ctx_put_words(const CtxRef& r, size_t word0, const T& v, int first, int last) {
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   SurfEB eb;
   const CtxRef cx = CtxRef::at(a.ctx, a.ctx_words, g);
   ctx_get(cx, CO_SV, sv);
-  ctx_get(cx, CO_EBM, static_cast<SurfEBMut&>(eb));
+  ctx_get_words(cx, CO_EBM, static_cast<SurfEBMut&>(eb), 0, (int)CW_EBM_FEED);
   ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
   const double* __restrict__ rec = a.pout + (size_t)g * pout_hru_stride(a.Nn);
   // the record the profile kernel has just written, or the one found on record for the final evaluation
@@ -701,7 +703,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     else if (rec[pout_key(a.Nn, slot ^ 1)] == sv.x) { sv.final_slot = slot ^ 1; sv.on_record = 1; need_solve = false; }
   }
   ctx_put(cx, CO_SV, sv);
-  ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
+  ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, (int)CW_EBM_FEED);
+  if (sv.stage == SurfSolve::DONE) ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), (int)CW_EBM_FEED, (int)CW_EBM);
   if (sv.stage == SurfSolve::DONE) a.hstate[g] = 2;
   else if (need_solve) { a.ts[g] = sv.x; a.pslot[g] = slot ^ 1; }     // keep the record just used, overwrite the older one
   list_append(a.list_next, a.count_next, a.list_cap, need_solve, a.hkey[g], g);
