@@ -320,3 +320,47 @@ def test_api_rejects_bad_calls():
     # QUICK_FLUX needs three nodes, FROZEN_SOIL excludes it (get_global_param.c:376-381,1151-1155)
     with pytest.raises(VicGpuError):
         Model(domain.make_domain(4, abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, QUICK_FLUX=1, Nnode=3), ntile=1))
+
+
+def test_month_long_trajectory(oracle_lib):
+    """A month of hourly steps through the spring thaw (every frozen-node pattern, rain on snow, melt-out), the GPU running
+    freely.  The model is discontinuous in its state (a Brent bracket that just fails, a fallback, a regime switch): over
+    hundreds of steps two correct implementations that differ in the last digits drift apart at such points -- here
+    1e-9 relative for 560 steps, then one HRU takes another branch (tools/exp/diverge.py; the oracle started from the
+    GPU's own state reproduces the GPU's next step to 1e-12).  So the long run is checked along the GPU's OWN trajectory:
+    every 12 hours the oracle is put on the GPU's state and both take the next step (1e-6 relative on every state row),
+    and the freely running oracle's accumulated outputs must still agree to 1e-4."""
+    from vic_amd.api import Model
+    kw = dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=2, frozen_compat=0)
+    nsteps, every = 720, 12
+    d, f, sf, dmy, sd0, si0 = _setup(kw, 24, 3, nsteps, 80)
+    free = oracle_lib.OracleModel(d)
+    free.set_state(sd0, si0)
+    shadow = oracle_lib.OracleModel(d)
+    gpu = Model(d)
+    gpu.set_state(sd0, si0)
+    gpu.push_forcing(f, sf, dmy)
+    cv = d.hru_dparams[C["HPD_CV"]]
+    cell = d.hru_iparams[C["HPI_CELL"]]
+    ro = np.zeros(d.ncell)
+    worst_shadow = 0.0
+    for s0 in range(0, nsteps, every):
+        sg_in, ig_in = gpu.get_state()
+        shadow.set_state(sg_in, ig_in)
+        shadow.step(f[s0], sf[s0], dmy[s0])
+        gpu.dist_prec(s0, 1)
+        ss, _ = shadow.get_state()
+        sg, _ = gpu.get_state()
+        ss[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
+        w, m = worst(ss, sg, "SD_", floor=1e-6)
+        assert w < TF_TOL, "step %d along the GPU trajectory: %s" % (s0, m)
+        worst_shadow = max(worst_shadow, w)
+        gpu.dist_prec(s0 + 1, every - 1)
+    for s in range(nsteps):
+        fo, co, eo = free.step(f[s], sf[s], dmy[s])
+        np.add.at(ro, cell, fo[C["FX_RUNOFF"]] * cv)
+    acc = gpu.get_accum()
+    assert gpu.get_cell_errors().sum() == 0
+    dmax = rel_diff(ro, acc[C["CA_RUNOFF"]], floor=1e-3).max()
+    print("month: shadow worst %.3e, accumulated runoff vs free oracle %.3e" % (worst_shadow, dmax))
+    assert dmax < 1e-4
