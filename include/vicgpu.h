@@ -298,7 +298,14 @@ int vicgpu_push_forcing(vicgpu_ctx *ctx, int nsteps,
                         const int *dmy);                /* [nsteps][VIC_NDMY] */
 
 /* ---- the hot path: for rec in [step0, step0+nsteps): dist_prec for every cell
- * (vicNl.c:506-543).  Asynchronous; vicgpu_synchronize waits. */
+ * (vicNl.c:506-543).  With QUICK_FLUX the call only enqueues work.  With the
+ * finite-difference soil profile (QUICK_FLUX off / FROZEN_SOIL) a step is a
+ * data-dependent number of kernel rounds, so the call returns when the last
+ * step's kernels have been issued, i.e. it blocks for most of the run time.
+ * vicgpu_synchronize waits for completion in both cases.
+ * Environment: VICGPU_CHUNKS=n runs n cell chunks as independent pipelines
+ * (own streams and host threads; results are identical for any n),
+ * VICGPU_TRACE / VICGPU_STATS print per-step round counts and timings. */
 int vicgpu_step(vicgpu_ctx *ctx, int step0, int nsteps);
 int vicgpu_synchronize(vicgpu_ctx *ctx);
 
@@ -314,8 +321,10 @@ int   vicgpu_set_stream(vicgpu_ctx *ctx, void *hip_stream);       /* compute str
 int   vicgpu_set_write_fluxes(vicgpu_ctx *ctx, int on);           /* 0: skip the per-HRU flux table (accumulators still kept) */
 void *vicgpu_device_ptr(vicgpu_ctx *ctx, int which);              /* VICGPU_PTR_* */
 enum { VICGPU_PTR_STATE_D = 0, VICGPU_PTR_STATE_I, VICGPU_PTR_FLUX, VICGPU_PTR_FORCING, VICGPU_PTR_ACCUM, VICGPU_PTR_CELL_OUT };
-/* average duration (ms) of the dominant kernel over the launches of the last
- * vicgpu_step call, measured with hipEvents on the compute stream */
+/* GPU time (ms) per model step of the last vicgpu_step call, measured with
+ * hipEvents on the library's streams: QUICK_FLUX: the step's HRU kernel, one
+ * event pair per step; finite-difference pipeline: all kernels of all steps
+ * of the call divided by the number of steps.  *nlaunch = steps covered. */
 int   vicgpu_last_kernel_ms(vicgpu_ctx *ctx, double *ms_per_launch, int *nlaunch);
 
 #ifdef __cplusplus
