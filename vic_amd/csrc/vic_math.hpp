@@ -202,15 +202,16 @@ struct Brent {
 // the state is a, b, c, d, e, fa, fb, fc and three counters, and one step is branch-light.  Where the reference would
 // misread a residual of exactly -999.0 as an error flag this treats it as the number it is.  Same operations otherwise.
 struct BrentLean {
-  enum Phase : int { EVAL_A0, EVAL_B0, EXP_A, EXP_B, MAIN, DONE };
-  double a, b, c, d, e, fa, fb, fc, x, result;
+  enum Phase : int { EVAL_A0, EVAL_B0, EXP_A, EXP_B, MAIN, DONE, FAILED };      // DONE: the root is b
+  double a, b, c, d, e, fa, fb, fc, x;
   int phase, i, j;
   VIC_DEV void start(double lower, double upper) {
     a = lower; b = upper; c = 0; d = 0; e = 0; fa = fb = fc = 0;
-    i = j = 0; result = ERROR_VAL;
+    i = j = 0;
     phase = EVAL_A0; x = a;
   }
-  VIC_DEV void fail() { result = ERROR_VAL; phase = DONE; }
+  VIC_DEV void fail() { phase = FAILED; }
+  VIC_DEV bool finished() const { return phase >= DONE; }
   VIC_DEV void advance(double fx) {
     if (phase == EVAL_A0 || phase == EXP_A) {              // residual at the lower end, next: the upper end
       fa = fx; x = b;
@@ -242,7 +243,7 @@ struct BrentLean {
     }
     const double tol = 2 * Brent::MACHEPS * fabs(b) + Brent::TTOL;
     const double m = 0.5 * (c - b);
-    if (fabs(m) <= tol || fb == 0) { result = b; phase = DONE; return; }
+    if (fabs(m) <= tol || fb == 0) { phase = DONE; return; }
     const bool bisect = fabs(e) < tol || fabs(fa) <= fabs(fb);
     const double s = fb / fa, q1 = fa / fc, r = fb / fc;
     const bool secant = (a == c);

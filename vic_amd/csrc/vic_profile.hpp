@@ -82,7 +82,9 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   const double threshold = 1.e-2;
 #define TL(j) Tl[(j) * 64 + lane]
 #define T0L(j) T0l[(j) * 64 + lane]
-#define CNT(j) outc[j]      // fallback counters of the current solve live in its output record (rarely touched)
+// the solution record of the current solve (pointers are recomputed where needed: they would cost six registers)
+#define REC() (a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn))
+#define CNT(j) (reinterpret_cast<int*>(REC() + Nn + 1)[j])      // fallback counters live in the record (rarely touched)
 
   enum { NODE = 1, BRENT = 2, FINISH = 3, IDLE = 4 };   // FINISH: solve done (or nothing yet), waiting at the gate
   int mode = FINISH;
@@ -91,9 +93,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   unsigned fbmask = 0;
   double maxdiff = threshold, oldT = 0;
   const double* __restrict__ blk = a.pin;
-  int* __restrict__ outc = nullptr;
-  double* __restrict__ out = a.pout;
-  double* __restrict__ key = a.pout;
+  int ps = 0;
   BrentLean br;
   SoilThermalEqn eq;
   br.phase = BrentLean::DONE;
@@ -131,11 +131,12 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
               fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
             } else ok = false;
           }
+          double* __restrict__ out = REC();
 #pragma unroll
           for (int k = 0; k < NN; k++)
             if (k < Nn) out[k] = TL(k);
           out[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
-          *key = T0L(0);                   // the trial surface temperature this record belongs to
+          a.pout[(size_t)hru * pout_hru_stride(Nn) + pout_key(Nn, ps)] = T0L(0);   // the trial surface temperature of this record
         }
         // next item: one atomic for all waiting lanes
         const int leader = __ffsll((long long)waiting) - 1;
@@ -155,13 +156,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
             hru = a.list[found];
           }
           blk = a.pin + (size_t)hru * Nn * PREC;
-          {
-            const int ps = a.pslot[hru];
-            double* __restrict__ rec = a.pout + (size_t)hru * pout_hru_stride(Nn);
-            out = rec + ps * pout_stride(Nn);
-            outc = reinterpret_cast<int*>(out + Nn + 1);
-            key = rec + pout_key(Nn, ps);
-          }
+          ps = a.pslot[hru];
           frozen_on = blk[PR_A] != 0.0;
           const double Ts = a.ts[hru];
 #pragma unroll
@@ -190,22 +185,21 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         node_done = true;
       } else {
         eq.TL = Tdn; eq.TU = Tup; eq.T0 = T0j; eq.moist = r[PR_MOIST]; eq.ice0 = r[PR_ICE];
-        eq.A = A; eq.B = B; eq.C = C; eq.D = D; eq.E = r[PR_E];
-        eq.max_moist = r[PR_MAXM]; eq.bubble = r[PR_BUB]; eq.expt = r[PR_EXPT];
-        eq.EXP_TRANS = a.EXP_TRANS; eq.node = j;
-        eq.prepare();
+        eq.A = A; eq.C = C; eq.D = D; eq.E = r[PR_E];
+        eq.max_moist = r[PR_MAXM];
+        eq.prepare(B, r[PR_BUB], r[PR_EXPT], j);
         br.start(T0j - SOIL_DT, T0j + SOIL_DT);
         mode = BRENT;
       }
     }
     TP(tp_node);
     if (mode == BRENT) {
-      const double fx = eq(br.x);
+      const double fx = eq.eval(br.x, a.EXP_TRANS != 0);
       TP(tp_eq);
       br.advance(fx);
-      if (br.phase == BrentLean::DONE) {
-        double rt = br.result;
-        if (is_error(rt)) {
+      if (br.finished()) {
+        double rt = br.b;
+        if (br.phase == BrentLean::FAILED) {
           if (a.TFALLBACK) { rt = eq.T0; fbmask |= (1u << j); CNT(j) += 1; }
           else { ok = false; mode = FINISH; }
         }
@@ -236,6 +230,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
 #undef TL
 #undef T0L
 #undef CNT
+#undef REC
 }
 
 }  // namespace vic

@@ -18,16 +18,16 @@ VIC_DEV double estimate_T1(double Ts, double T1_old, double T2, double D1, doubl
 // temperature out of the Brent iteration (same operations, same bits): the divisor and exponent of the
 // freezing-point-depression curve (maximum_unfrozen_water), B*(TL-TU) and the |TL-TU| > 5 test of the node-1 special case.
 struct SoilThermalEqn {
-  double TL, TU, T0, moist, max_moist, bubble, expt, ice0, A, B, C, D, E;
+  double TL, TU, T0, moist, max_moist, ice0, A, C, D, E;
   double den, yexp, flux_term1;
-  int EXP_TRANS, node, steep;
-  VIC_DEV void prepare() {
+  int steep;
+  VIC_DEV void prepare(double B, double bubble, double expt, int node) {
     den = 9.81 * bubble / 100.;
     yexp = -(2.0 / (expt - 3.0));
     flux_term1 = B * (TL - TU);
     steep = (node == 1 && fabs(TL - TU) > 5.) ? 1 : 0;
   }
-  VIC_DEV double operator()(double T) const {
+  VIC_DEV double eval(double T, bool EXP_TRANS) const {
     double ice;
     if (T < 0.) {
       double u = max_moist * pow_pos((-LF * T) / 273.16 / den, yexp);       // maximum_unfrozen_water, T <= 0 branch
