@@ -321,6 +321,31 @@ int   vicgpu_set_stream(vicgpu_ctx *ctx, void *hip_stream);       /* compute str
 int   vicgpu_set_write_fluxes(vicgpu_ctx *ctx, int on);           /* 0: skip the per-HRU flux table (accumulators still kept) */
 void *vicgpu_device_ptr(vicgpu_ctx *ctx, int which);              /* VICGPU_PTR_* */
 enum { VICGPU_PTR_STATE_D = 0, VICGPU_PTR_STATE_I, VICGPU_PTR_FLUX, VICGPU_PTR_FORCING, VICGPU_PTR_ACCUM, VICGPU_PTR_CELL_OUT };
+/* ---- test hook: the pure functions of the path, evaluated one by one ----------
+ * (SURVEY.md 8(c) fixture plan (i)).  in: double[n][VICGPU_PURE_NIN], out: double[n].
+ * Functions that read cell parameters or options use cell 0 of the domain and the
+ * context's options.  The reference harness (oracle/ref_build) and the oracle
+ * export the same hook as vicref_pure / vicorc_pure. */
+enum {
+  VICGPU_PURE_SVP = 0,            /* svp.c:7: T */
+  VICGPU_PURE_SVP_SLOPE,          /* svp.c:26: T */
+  VICGPU_PURE_CALC_RAINONLY,      /* calc_rainonly.c:12: air_temp, prec, MAX_SNOW_TEMP, MIN_RAIN_TEMP */
+  VICGPU_PURE_SNOW_ALBEDO,        /* snow_utility.c:229: new_snow, swq, depth, albedo, cold_content, dt, last_snow, MELTING */
+  VICGPU_PURE_NEW_SNOW_DENSITY,   /* snow_utility.c:199: air_temp */
+  VICGPU_PURE_STABILITY,          /* StabilityCorrection.c:44: Z, d, TSurf, Tair, Wind, Z0 */
+  VICGPU_PURE_PENMAN,             /* penman.c:96: tair, elevation, rad, vpd, ra, rc, rarc */
+  VICGPU_PURE_CALC_RC,            /* penman.c:44: rs, net_short, RGL, tair, vpd, lai, gsm_inv, ref_crop */
+  VICGPU_PURE_ESTIMATE_T1,        /* estimate_T1.c:8: Ts, T1_old, T2, D1, D2, kappa1, kappa2, Cs2 (Cs1 is unused: = Cs2), dp, delta_t */
+  VICGPU_PURE_SOIL_CONDUCTIVITY,  /* soil_conduction.c:7: moist, Wu, soil_dens_min, bulk_dens_min, quartz, soil_density, bulk_density, organic */
+  VICGPU_PURE_VOL_HEAT_CAPACITY,  /* soil_conduction.c:108: soil_fract, water_fract, ice_fract, organic_fract */
+  VICGPU_PURE_MAX_UNFROZEN_WATER, /* soil_conduction.c: T, max_moist, bubble, expt */
+  VICGPU_PURE_LINEAR_INTERP,      /* x, lx, ux, ly, uy */
+  VICGPU_PURE_VEG_HEIGHT,         /* calc_veg_params.c:26: displacement, L (NaN for L = 0) */
+  VICGPU_PURE_NFN
+};
+#define VICGPU_PURE_NIN 10
+int   vicgpu_debug_pure(vicgpu_ctx *ctx, int fn, int n, const double *in, double *out);
+
 /* GPU time (ms) per model step of the last vicgpu_step call, measured with
  * hipEvents on the library's streams: QUICK_FLUX: the step's HRU kernel, one
  * event pair per step; finite-difference pipeline: all kernels of all steps

@@ -688,6 +688,44 @@ double vicorc_run(void *hv, int nsteps, const double *forcing, const unsigned ch
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* the pure functions of the path one by one (include/vicgpu.h VICGPU_PURE_*) */
+double orc_snow_albedo_x(const orc_model *m, double new_snow, double swq, double depth, double albedo, double cold_content,
+                         double dt, int last_snow, int MELTING, const orc_soil *sc);
+double orc_new_snow_density_x(const orc_model *m, double air_temp);
+double orc_estimate_T1_x(double Ts, double T1_old, double T2, double D1, double D2, double kappa1, double kappa2, double Cs1, double Cs2,
+                         double dp, double delta_t);
+
+int vicorc_pure(void *hv, int fn, int n, const double *in, double *out) {
+  vicorc_handle *h = (vicorc_handle *)hv;
+  int i;
+  if (!h || n < 0 || !in || !out) return -1;
+  for (i = 0; i < n; i++) {
+    const double *a = in + (size_t)i * VICGPU_PURE_NIN;
+    double r;
+    switch (fn) {
+      case VICGPU_PURE_SVP: r = orc_svp(a[0]); break;
+      case VICGPU_PURE_SVP_SLOPE: r = orc_svp_slope(a[0]); break;
+      case VICGPU_PURE_CALC_RAINONLY: r = orc_calc_rainonly(&h->model, a[0], a[1], a[2], a[3]); break;
+      case VICGPU_PURE_SNOW_ALBEDO:
+        if (!h->soil) return -1;
+        r = orc_snow_albedo_x(&h->model, a[0], a[1], a[2], a[3], a[4], a[5], (int)a[6], a[7] != 0.0, &h->soil[0]); break;
+      case VICGPU_PURE_NEW_SNOW_DENSITY: r = orc_new_snow_density_x(&h->model, a[0]); break;
+      case VICGPU_PURE_STABILITY: r = orc_stability_correction(a[0], a[1], a[2], a[3], a[4], a[5]); break;
+      case VICGPU_PURE_PENMAN: r = orc_penman(a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
+      case VICGPU_PURE_CALC_RC: r = orc_calc_rc(a[0], a[1], (float)a[2], a[3], a[4], a[5], a[6], a[7] != 0.0); break;
+      case VICGPU_PURE_ESTIMATE_T1: r = orc_estimate_T1_x(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[7], a[8], a[9]); break;
+      case VICGPU_PURE_SOIL_CONDUCTIVITY: r = orc_soil_conductivity(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]); break;
+      case VICGPU_PURE_VOL_HEAT_CAPACITY: r = orc_volumetric_heat_capacity(a[0], a[1], a[2], a[3]); break;
+      case VICGPU_PURE_MAX_UNFROZEN_WATER: r = orc_maximum_unfrozen_water(a[0], a[1], a[2], a[3]); break;
+      case VICGPU_PURE_LINEAR_INTERP: r = orc_linear_interp(a[0], a[1], a[2], a[3], a[4]); break;
+      case VICGPU_PURE_VEG_HEIGHT: r = orc_calc_veg_height(a[0], a[1]); break;
+      default: return -1;
+    }
+    out[i] = r;
+  }
+  return 0;
+}
+
 int vicorc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -482,3 +482,9 @@ double orc_calc_surf_energy_bal(const orc_model *m, double Le, double LongUnderI
   }
   return Tsurf;
 }
+
+/* exported wrapper for the pure-function hook (vicorc_pure) */
+double orc_estimate_T1_x(double Ts, double T1_old, double T2, double D1, double D2, double kappa1, double kappa2, double Cs1, double Cs2,
+                         double dp, double delta_t) {
+  return orc_estimate_T1(Ts, T1_old, T2, D1, D2, kappa1, kappa2, Cs1, Cs2, dp, delta_t);
+}

@@ -101,6 +101,19 @@ class _Model:
         getattr(self.lib, self.prefix + "step")(self.h, _d(forcing), _u(snowflag), _i(dmy), _d(fx), _d(co), _i(ce), nthreads)
         return fx, co, ce
 
+    def pure(self, fn, inputs):
+        """Test hook (<prefix>pure): one pure function of the path for every row of inputs [n][<= 10]."""
+        inputs = np.asarray(inputs, dtype=np.float64)
+        inp = np.zeros((inputs.shape[0], 10))
+        inp[:, :inputs.shape[1]] = inputs
+        out = np.zeros(inp.shape[0])
+        f = getattr(self.lib, self.prefix + "pure")
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, _dp]
+        rc = f(self.h, int(fn), inp.shape[0], _d(inp), _d(out))
+        assert rc == 0, rc
+        return out
+
     def run(self, forcing, snowflag, dmy, nthreads=1):
         forcing = np.ascontiguousarray(forcing); snowflag = np.ascontiguousarray(snowflag)
         dmy = np.ascontiguousarray(dmy, dtype=np.int32)

@@ -473,6 +473,39 @@ double vicref_run(void *hv, int nsteps, const double *forcing, const unsigned ch
   return std::chrono::duration<double>(t1 - t0).count();
 }
 
+/* the pure functions of the path one by one (include/vicgpu.h VICGPU_PURE_*): the reference's own functions */
+int vicref_pure(void *hv, int fn, int n, const double *in, double *out) {
+  vicref_handle *h = (vicref_handle *)hv;
+  if (!h || n < 0 || !in || !out) return -1;
+  const ProgramState *st = &h->state;
+  const soil_con_struct *sc = h->cells.empty() ? NULL : &h->cells[0].soil_con;
+  for (int i = 0; i < n; i++) {
+    const double *a = in + (size_t)i * VICGPU_PURE_NIN;
+    double r;
+    switch (fn) {
+      case VICGPU_PURE_SVP: r = svp(a[0]); break;
+      case VICGPU_PURE_SVP_SLOPE: r = svp_slope(a[0]); break;
+      case VICGPU_PURE_CALC_RAINONLY: r = calc_rainonly(a[0], a[1], a[2], a[3], 1.0, st); break;
+      case VICGPU_PURE_SNOW_ALBEDO:
+        if (!sc) return -1;
+        r = snow_albedo(a[0], a[1], a[2], a[3], a[4], a[5], (int)a[6], a[7] != 0.0, sc, st); break;
+      case VICGPU_PURE_NEW_SNOW_DENSITY: r = new_snow_density(a[0], st); break;
+      case VICGPU_PURE_STABILITY: r = StabilityCorrection(a[0], a[1], a[2], a[3], a[4], a[5]); break;
+      case VICGPU_PURE_PENMAN: r = penman(a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
+      case VICGPU_PURE_CALC_RC: r = calc_rc(a[0], a[1], (float)a[2], a[3], a[4], a[5], a[6], a[7] != 0.0 ? TRUE : FALSE); break;
+      case VICGPU_PURE_ESTIMATE_T1: r = estimate_T1(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[7], a[8], a[9]); break;
+      case VICGPU_PURE_SOIL_CONDUCTIVITY: r = soil_conductivity(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]); break;
+      case VICGPU_PURE_VOL_HEAT_CAPACITY: r = volumetric_heat_capacity(a[0], a[1], a[2], a[3]); break;
+      case VICGPU_PURE_MAX_UNFROZEN_WATER: r = maximum_unfrozen_water(a[0], a[1], a[2], a[3]); break;
+      case VICGPU_PURE_LINEAR_INTERP: r = linear_interp(a[0], a[1], a[2], a[3], a[4]); break;
+      case VICGPU_PURE_VEG_HEIGHT: r = calc_veg_height(a[0], a[1]); break;
+      default: return -1;
+    }
+    out[i] = r;
+  }
+  return 0;
+}
+
 int vicref_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -30,7 +30,25 @@ SCENARIOS = {
 }
 
 
+def make_pure():
+    """Known-answer vectors of the pure functions (tests/pure_inputs.py) from the reference's own functions."""
+    from tests.pure_inputs import pure_inputs, OPTION_SETS
+    inputs = pure_inputs()
+    for oname, kw in OPTION_SETS.items():
+        opt = abi.default_options(**kw)
+        d = domain.make_domain(2, opt, ntile=1)
+        ref = RefModel(d, "plain")
+        out = {}
+        for fn, inp in inputs.items():
+            out["in_%d" % fn] = inp
+            out["out_%d" % fn] = ref.pure(fn, inp)
+        ref.close()
+        np.savez_compressed(os.path.join(HERE, "pure_%s.npz" % oname), **out)
+        print("pure_%s" % oname, "functions", len(inputs))
+
+
 def main():
+    make_pure()
     for name, (kw, variant, ncell, ntile, glacier, nsteps, doy, stride) in SCENARIOS.items():
         opt = abi.default_options(**kw)
         d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)

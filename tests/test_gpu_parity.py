@@ -364,3 +364,24 @@ def test_month_long_trajectory(oracle_lib):
     dmax = rel_diff(ro, acc[C["CA_RUNOFF"]], floor=1e-3).max()
     print("month: shadow worst %.3e, accumulated runoff vs free oracle %.3e" % (worst_shadow, dmax))
     assert dmax < 1e-4
+
+
+@pytest.mark.parametrize("oname", ["default", "alt"])
+def test_pure_functions_on_device(oname):
+    """The device versions of the pure functions against the reference's known-answer vectors (tests/golden/pure_*.npz).
+    Closed-form arithmetic must agree to the last bits; exp / log / pow differ from glibc in the last ulps (and the freezing
+    curve uses exp(y ln x)), hence 1e-12 relative."""
+    import os
+    from vic_amd.api import Model
+    from tests.pure_inputs import OPTION_SETS
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pure_%s.npz" % oname))
+    opt = abi.default_options(**OPTION_SETS[oname])
+    d = domain.make_domain(2, opt, ntile=1)
+    m = Model(d)
+    names = {v: k for k, v in C.items() if k.startswith("VICGPU_PURE_") and k not in ("VICGPU_PURE_NFN", "VICGPU_PURE_NIN")}
+    for fn in range(C["VICGPU_PURE_NFN"]):
+        inp, exp = g["in_%d" % fn], g["out_%d" % fn]
+        got = m.debug_pure(fn, inp)
+        dmax = rel_diff(got, exp, 1e-300).max()
+        print(names[fn], "max rel diff %.2e" % dmax)
+        assert dmax < 1e-12, names[fn]

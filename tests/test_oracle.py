@@ -131,3 +131,31 @@ def test_root_brent_known_cubic(oracle_lib):
     h = FN(lambda x, ctx: -999.0 if x < -0.5 else x - 0.25)
     r = lib.orc_root_brent(-2.0, 1.0, h, None)
     assert abs(r - 0.25) < 2e-7
+
+
+PURE_NAMES = {v: k for k, v in C.items() if k.startswith("VICGPU_PURE_") and k not in ("VICGPU_PURE_NFN", "VICGPU_PURE_NIN")}
+
+
+@pytest.mark.parametrize("oname", ["default", "alt"])
+def test_pure_functions_against_golden(oname, oracle_lib, ref_available):
+    """Known-answer vectors of the pure functions of the path (SURVEY.md 8(c) fixture plan (i)): 256 seeded inputs per
+    function incl. the branch points, outputs of the reference's own functions (tests/golden/pure_*.npz, generated by
+    tests/golden/make_golden.py); the oracle must reproduce them bit for bit, and so must the reference when it is here."""
+    import os
+    from tests.pure_inputs import pure_inputs, OPTION_SETS
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pure_%s.npz" % oname))
+    opt = abi.default_options(**OPTION_SETS[oname])
+    d = domain.make_domain(2, opt, ntile=1)
+    orc = oracle_lib.OracleModel(d)
+    ref = oracle_lib.RefModel(d, "plain") if ref_available else None
+    inputs = pure_inputs()
+    assert len(inputs) == C["VICGPU_PURE_NFN"]
+    for fn, inp in inputs.items():
+        assert np.array_equal(inp, g["in_%d" % fn]), "fixture inputs of %s are stale" % PURE_NAMES[fn]
+        exp = g["out_%d" % fn]
+        got = orc.pure(fn, inp)
+        assert np.array_equal(got, exp, equal_nan=True), "%s: oracle differs, worst %.3e" % (PURE_NAMES[fn], rel_diff(got, exp, 1e-300).max())
+        if ref is not None:
+            assert np.array_equal(ref.pure(fn, inp), exp, equal_nan=True), PURE_NAMES[fn]
+    if ref is not None:
+        ref.close()

@@ -59,6 +59,7 @@ def load_library():
         "vicgpu_set_write_fluxes": (ctypes.c_int, [vp, ctypes.c_int]),
         "vicgpu_device_ptr": (vp, [vp, ctypes.c_int]),
         "vicgpu_last_kernel_ms": (ctypes.c_int, [vp, _dp, _ip]),
+        "vicgpu_debug_pure": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
@@ -74,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "vicgpu_abi_version", "vicgpu_create", "vicgpu_destroy", "vicgpu_last_error", "vicgpu_set_veglib", "vicgpu_set_domain",
     "vicgpu_set_state", "vicgpu_get_state", "vicgpu_push_forcing", "vicgpu_step", "vicgpu_synchronize", "vicgpu_get_fluxes",
     "vicgpu_get_cell_outputs", "vicgpu_get_accum", "vicgpu_reset_accum", "vicgpu_get_cell_errors", "vicgpu_set_stream",
-    "vicgpu_set_write_fluxes", "vicgpu_device_ptr", "vicgpu_last_kernel_ms",
+    "vicgpu_set_write_fluxes", "vicgpu_device_ptr", "vicgpu_last_kernel_ms", "vicgpu_debug_pure",
 ]
 
 
@@ -180,6 +181,15 @@ class Model:
 
     def set_write_fluxes(self, on):
         self._chk(self.lib.vicgpu_set_write_fluxes(self.h, int(bool(on))))
+
+    def debug_pure(self, fn, inputs):
+        """Test hook (vicgpu_debug_pure): one pure function of the path for every row of inputs [n][VICGPU_PURE_NIN]."""
+        inp = np.zeros((len(inputs), C["VICGPU_PURE_NIN"]) if "VICGPU_PURE_NIN" in C else (len(inputs), 10))
+        inputs = np.asarray(inputs, dtype=np.float64)
+        inp[:, :inputs.shape[1]] = inputs
+        out = np.zeros(inp.shape[0])
+        self._chk(self.lib.vicgpu_debug_pure(self.h, int(fn), inp.shape[0], _d(inp), _d(out)))
+        return out
 
     def last_kernel_ms(self):
         ms = ctypes.c_double(0)

@@ -714,6 +714,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+// ------------------------------------------------------------------------------------------------ test hook
+struct DArgs { Opt o; const double* cell_params; int ncell, fn, n; const double* in; double* out; };
+
+__global__ __launch_bounds__(64) void vic_debug_pure(const DArgs d) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= d.n) return;
+  const double* a = d.in + (size_t)i * VICGPU_PURE_NIN;
+  CellView cv{d.cell_params, d.ncell, 0, d.o.Nnode, d.o.Nband};
+  double r = NAN;
+  switch (d.fn) {
+    case VICGPU_PURE_SVP: r = svp(a[0]); break;
+    case VICGPU_PURE_SVP_SLOPE: r = svp_slope(a[0]); break;
+    case VICGPU_PURE_CALC_RAINONLY: r = calc_rainonly(d.o, a[0], a[1], a[2], a[3]); break;
+    case VICGPU_PURE_SNOW_ALBEDO: r = snow_albedo(d.o, cv, a[0], a[1], a[2], a[3], a[4], a[5], (int)a[6], a[7] != 0.0 ? 1 : 0); break;
+    case VICGPU_PURE_NEW_SNOW_DENSITY: r = new_snow_density(d.o, a[0]); break;
+    case VICGPU_PURE_STABILITY: r = stability_correction(a[0], a[1], a[2], a[3], a[4], a[5]); break;
+    case VICGPU_PURE_PENMAN: r = penman(a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
+    case VICGPU_PURE_CALC_RC: r = calc_rc(a[0], a[1], (float)a[2], a[3], a[4], a[5], a[6], a[7] != 0.0); break;
+    case VICGPU_PURE_ESTIMATE_T1: r = estimate_T1(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]); break;
+    case VICGPU_PURE_SOIL_CONDUCTIVITY: r = soil_conductivity(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]); break;
+    case VICGPU_PURE_VOL_HEAT_CAPACITY: r = volumetric_heat_capacity(a[0], a[1], a[2], a[3]); break;
+    case VICGPU_PURE_MAX_UNFROZEN_WATER: r = maximum_unfrozen_water(a[0], a[1], a[2], a[3]); break;
+    case VICGPU_PURE_LINEAR_INTERP: r = linear_interp(a[0], a[1], a[2], a[3], a[4]); break;
+    case VICGPU_PURE_VEG_HEIGHT: r = calc_veg_height(a[0], a[1]); break;
+    default: break;
+  }
+  d.out[i] = r;
+}
+
 // ------------------------------------------------------------------------------------------------ cell kernel
 struct CArgs {
   int ncell, nhru;
@@ -1335,6 +1364,24 @@ int vicgpu_reset_accum(vicgpu_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemsetAsync(c->d_accum, 0, sizeof(double) * CA_NROW * c->ncell, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_cell_err, 0, sizeof(int) * c->ncell, c->stream));
+  return VICGPU_OK;
+}
+
+int vicgpu_debug_pure(vicgpu_ctx* c, int fn, int n, const double* in, double* out) {
+  if (!c || !c->d_cp || fn < 0 || fn >= VICGPU_PURE_NFN || n <= 0 || !in || !out) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  double *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(c, hipMalloc(&d_in, sizeof(double) * (size_t)n * VICGPU_PURE_NIN));
+  HIPCHK(c, hipMalloc(&d_out, sizeof(double) * (size_t)n));
+  HIPCHK(c, hipMemcpy(d_in, in, sizeof(double) * (size_t)n * VICGPU_PURE_NIN, hipMemcpyHostToDevice));
+  DArgs d;
+  d.o = c->o; d.cell_params = c->d_cp; d.ncell = c->ncell; d.fn = fn; d.n = n; d.in = d_in; d.out = d_out;
+  hipLaunchKernelGGL(vic_debug_pure, dim3((n + 63) / 64), dim3(64), 0, c->stream, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+  HIPIGN(hipFree(d_in)); HIPIGN(hipFree(d_out));
+  HIPCHK(c, e);
   return VICGPU_OK;
 }
 
