@@ -321,6 +321,16 @@ int   vicgpu_set_stream(vicgpu_ctx *ctx, void *hip_stream);       /* compute str
 int   vicgpu_set_write_fluxes(vicgpu_ctx *ctx, int on);           /* 0: skip the per-HRU flux table (accumulators still kept) */
 void *vicgpu_device_ptr(vicgpu_ctx *ctx, int which);              /* VICGPU_PTR_* */
 enum { VICGPU_PTR_STATE_D = 0, VICGPU_PTR_STATE_I, VICGPU_PTR_FLUX, VICGPU_PTR_FORCING, VICGPU_PTR_ACCUM, VICGPU_PTR_CELL_OUT };
+/* ---- glacier mass balance: what accumulateGlacierMassBalance.c:53-66 does when an
+ * accumulation interval ends (the date test stays with the driver, like the opening of the
+ * window): per cell the quadratic best fit of the accumulated mass balance of its glacier
+ * HRUs against band elevation (GlacierMassBalanceResult.c:34-73, GraphingEquation.c:8-125;
+ * 1 point: constant, 2 points: line), then -- if reset -- cum_mass_balance = 0 for every
+ * glacier HRU (resetAccumulationValues).  eq: double[GMB_NROW][ncell]; cells without a
+ * valid point get the default equation (0, 0, 0, fitError -1). */
+enum { GMB_B0 = 0, GMB_B1, GMB_B2, GMB_FIT_ERROR, GMB_NROW };
+int   vicgpu_glacier_mass_balance_fit(vicgpu_ctx *ctx, double *eq, int reset);
+
 /* ---- test hook: the pure functions of the path, evaluated one by one ----------
  * (SURVEY.md 8(c) fixture plan (i)).  in: double[n][VICGPU_PURE_NIN], out: double[n].
  * Functions that read cell parameters or options use cell 0 of the domain and the

@@ -688,6 +688,27 @@ double vicorc_run(void *hv, int nsteps, const double *forcing, const unsigned ch
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* accumulateGlacierMassBalance.c:53-66 at the end of an accumulation interval: fit per cell, then reset */
+void orc_glacier_mass_balance_fit(const orc_soil *sc, orc_hru **hrus, int nhru, double *eq);
+
+int vicorc_glacier_fit(void *hv, double *eq, int reset) {
+  vicorc_handle *h = (vicorc_handle *)hv;
+  int c, k;
+  if (!h || !eq || !h->hru) return -1;
+  for (c = 0; c < h->ncell; c++) {
+    orc_hru *list[VIC_MAX_BANDS * 8 + 8];
+    double e[4];
+    int n = 0;
+    for (k = h->cell_off[c]; k < h->cell_off[c + 1] && n < (int)(sizeof(list) / sizeof(list[0])); k++) list[n++] = &h->hru[h->cell_list[k]];
+    orc_glacier_mass_balance_fit(&h->soil[c], list, n, e);
+    for (k = 0; k < 4; k++) eq[(size_t)k * h->ncell + c] = e[k];
+    if (reset)
+      for (k = 0; k < n; k++)
+        if (list[k]->is_glacier) list[k]->glac.cum_mass_balance = 0;
+  }
+  return 0;
+}
+
 /* the pure functions of the path one by one (include/vicgpu.h VICGPU_PURE_*) */
 double orc_snow_albedo_x(const orc_model *m, double new_snow, double swq, double depth, double albedo, double cold_content,
                          double dt, int last_snow, int MELTING, const orc_soil *sc);

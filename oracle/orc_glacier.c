@@ -668,3 +668,61 @@ int orc_surface_fluxes_glac(const orc_model *m, orc_hru *h, const orc_soil *sc, 
   h->runoff += (h->glac.outflow * 1000.);
   return 0;
 }
+
+/* GlacierMassBalanceResult::GlacierMassBalanceResult (GlacierMassBalanceResult.c:34-73) + GraphingEquation
+ * (GraphingEquation.c:8-125): quadratic least-squares fit of accumulated mass balance against band elevation through
+ * closed-form normal equations.  hrus: the cell's HRUs in hruList order.  eq[4] = b0, b1, b2, fitError. */
+void orc_glacier_mass_balance_fit(const orc_soil *sc, orc_hru **hrus, int nhru, double *eq) {
+  double X[VIC_MAX_BANDS * 8 + 8], Y[VIC_MAX_BANDS * 8 + 8];
+  int np = 0, i, j, k;
+  double b0 = 0, b1 = 0, b2 = 0, fit = -1;
+  for (i = 0; i < nhru; i++) {
+    const orc_hru *h = hrus[i];
+    if (h->is_glacier && !isnan(h->glac.cum_mass_balance)) {           /* IS_VALID */
+      const double x = (double)(float)sc->BandElev[h->band];
+      int found = 0;
+      for (j = 0; j < np; j++)
+        if (X[j] == x) { Y[j] += h->glac.cum_mass_balance; found = 1; }
+      if (!found && np < (int)(sizeof(X) / sizeof(X[0]))) { X[np] = x; Y[np] = h->glac.cum_mass_balance; np++; }
+    }
+  }
+  /* "Remove graph points which are meaningless": elevation 0 (lastElevation stays 0, GlacierMassBalanceResult.c:58-66) */
+  for (i = 0, k = 0; i < np; i++)
+    if (!(X[i] == 0 && X[i] <= 0)) { X[k] = X[i]; Y[k] = Y[i]; k++; }
+  np = k;
+  if (np == 1) { b0 = Y[0]; b1 = 0; b2 = 0; }
+  else if (np == 2) {
+    double slope = (Y[1] - Y[0]) / (X[1] - X[0]);
+    b0 = Y[0] - slope * X[0]; b1 = slope; b2 = 0;
+  } else if (np >= 3) {
+    double sumx4 = 0, sumx3 = 0, sumx2 = 0, sumx1 = 0, det, inv[3][3], a[3] = {0, 0, 0};
+    const int size = np;
+    for (i = 0; i < np; i++) {
+      sumx4 += X[i] * X[i] * X[i] * X[i];
+      sumx3 += X[i] * X[i] * X[i];
+      sumx2 += X[i] * X[i];
+      sumx1 += X[i];
+    }
+    det = (sumx4 * sumx2 * size) + (sumx3 * sumx1 * sumx2) + (sumx2 * sumx3 * sumx1) - (sumx2 * sumx2 * sumx2) - (sumx1 * sumx1 * sumx4)
+          - (size * sumx3 * sumx3);
+    inv[0][0] = size * sumx2 - sumx1 * sumx1; inv[0][1] = -(size * sumx3 - sumx1 * sumx2); inv[0][2] = sumx1 * sumx3 - sumx2 * sumx2;
+    inv[1][0] = -(size * sumx3 - sumx2 * sumx1); inv[1][1] = size * sumx4 - sumx2 * sumx2; inv[1][2] = -(sumx1 * sumx4 - sumx3 * sumx2);
+    inv[2][0] = sumx1 * sumx3 - sumx2 * sumx2; inv[2][1] = -(sumx1 * sumx4 - sumx2 * sumx3); inv[2][2] = sumx2 * sumx4 - sumx3 * sumx3;
+    for (i = 0; i < 3; i++) {
+      for (j = 0; j < np; j++) {
+        const double stuff = inv[i][0] * (X[j] * X[j]) + inv[i][1] * X[j] + inv[i][2] * 1;
+        a[i] += stuff * Y[j];
+      }
+      a[i] /= det;
+    }
+    b0 = a[2]; b1 = a[1]; b2 = a[0];
+  }
+  if (np > 0) {
+    fit = 0;
+    for (i = 0; i < np; i++) {
+      const double curve = b0 + b1 * X[i] + b2 * (X[i] * X[i]);
+      fit += fabs(curve - Y[i]);
+    }
+  }
+  eq[0] = b0; eq[1] = b1; eq[2] = b2; eq[3] = fit;
+}

@@ -101,6 +101,15 @@ class _Model:
         getattr(self.lib, self.prefix + "step")(self.h, _d(forcing), _u(snowflag), _i(dmy), _d(fx), _d(co), _i(ce), nthreads)
         return fx, co, ce
 
+    def glacier_fit(self, reset=True):
+        eq = np.zeros((C["GMB_NROW"], self.dom.ncell))
+        f = getattr(self.lib, self.prefix + "glacier_fit")
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int]
+        rc = f(self.h, _d(eq), int(bool(reset)))
+        assert rc == 0, rc
+        return eq
+
     def pure(self, fn, inputs):
         """Test hook (<prefix>pure): one pure function of the path for every row of inputs [n][<= 10]."""
         inputs = np.asarray(inputs, dtype=np.float64)

@@ -26,6 +26,7 @@
 #endif
 
 #include "vicgpu.h"
+#include "GlacierMassBalanceResult.h"
 
 struct vicref_handle {
   ProgramState state;
@@ -40,6 +41,9 @@ struct vicref_handle {
 };
 
 static inline double cpv(const vicref_handle *h, int row, int c) { return h->cp[(size_t)row * h->ncell + c]; }
+
+/* accumulateGlacierMassBalance.c:5 (C++ linkage, not declared in a header) */
+void resetAccumulationValues(std::vector<HRU>* hruList);
 
 extern "C" {
 
@@ -471,6 +475,24 @@ double vicref_run(void *hv, int nsteps, const double *forcing, const unsigned ch
     vicref_step(hv, forcing + s * fstride, snowflag ? snowflag + s * sstride : NULL, dmyv + (size_t)s * VIC_NDMY, NULL, NULL, NULL, nthreads);
   auto t1 = std::chrono::steady_clock::now();
   return std::chrono::duration<double>(t1 - t0).count();
+}
+
+/* the reference's own GlacierMassBalanceResult + resetAccumulationValues (accumulateGlacierMassBalance.c:53-66) */
+int vicref_glacier_fit(void *hv, double *eq, int reset) {
+  vicref_handle *h = (vicref_handle *)hv;
+  if (!h || !eq) return -1;
+  dmy_struct d;
+  memset(&d, 0, sizeof(d));
+  for (int c = 0; c < h->ncell; c++) {
+    cell_info_struct &cell = h->cells[c];
+    GlacierMassBalanceResult result(cell.prcp.hruList, &cell.soil_con, d);
+    eq[(size_t)GMB_B0 * h->ncell + c] = result.equation.b0;
+    eq[(size_t)GMB_B1 * h->ncell + c] = result.equation.b1;
+    eq[(size_t)GMB_B2 * h->ncell + c] = result.equation.b2;
+    eq[(size_t)GMB_FIT_ERROR * h->ncell + c] = result.equation.fitError;
+    if (reset) resetAccumulationValues(&cell.prcp.hruList);
+  }
+  return 0;
 }
 
 /* the pure functions of the path one by one (include/vicgpu.h VICGPU_PURE_*): the reference's own functions */

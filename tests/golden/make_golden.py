@@ -47,8 +47,30 @@ def make_pure():
         print("pure_%s" % oname, "functions", len(inputs))
 
 
+def make_gmb():
+    """Glacier mass-balance fit (accumulateGlacierMassBalance.c:53-66): the reference's state before the fit and its fit."""
+    from tests.test_oracle import GMB_CASES, _gmb_setup
+    for name, kw, glacier in GMB_CASES:
+        d, f, sf, dmy = _gmb_setup(kw, glacier)
+        ref = RefModel(d, "plain")
+        ref.init_state(f[0], dmy[0], d.init_moist)
+        sd0, si0 = ref.get_state()
+        isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+        sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
+        ref.set_state(sd0, si0)
+        for s in range(f.shape[0]):
+            ref.step(f[s], sf[s], dmy[s])
+        sd, si = ref.get_state()
+        eq = ref.glacier_fit(reset=True)
+        ref.close()
+        np.savez_compressed(os.path.join(HERE, "gmb_%s.npz" % name), sd=sd, si=si, eq=eq, cell_params=d.cell_params,
+                            hru_iparams=d.hru_iparams)
+        print("gmb_%s" % name, eq[:, 0])
+
+
 def main():
     make_pure()
+    make_gmb()
     for name, (kw, variant, ncell, ntile, glacier, nsteps, doy, stride) in SCENARIOS.items():
         opt = abi.default_options(**kw)
         d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)

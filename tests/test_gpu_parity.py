@@ -385,3 +385,38 @@ def test_pure_functions_on_device(oname):
         dmax = rel_diff(got, exp, 1e-300).max()
         print(names[fn], "max rel diff %.2e" % dmax)
         assert dmax < 1e-12, names[fn]
+
+
+@pytest.mark.parametrize("name,kw,glacier", [("one_point", dict(FULL_ENERGY=1, Nband=3), True), ("two_points", dict(FULL_ENERGY=1, Nband=2), "all"),
+                                            ("quadratic_5_bands", dict(FULL_ENERGY=1, Nband=5), "all")])
+def test_glacier_mass_balance_fit(name, kw, glacier, oracle_lib):
+    """vicgpu_glacier_mass_balance_fit against the oracle (itself bit-exact against the reference's
+    GlacierMassBalanceResult, tests/test_oracle.py) from the same accumulated state: the fit is +, -, x, / only, so the
+    device result must be identical."""
+    from vic_amd.api import Model
+    opt = abi.default_options(**kw)
+    d = domain.make_domain(6, opt, ntile=2, glacier_top_band=glacier)
+    nsteps = 72
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=170)
+    sd0, si0 = init_state.initial_state(d, f[0])
+    isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+    sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    for s in range(nsteps):
+        orc.step(f[s], sf[s], dmy[s])
+    so, io = orc.get_state()
+    gpu = Model(d)
+    gpu.set_state(so, io)                                   # fit from the oracle's accumulated state
+    eg, eo = gpu.glacier_mass_balance_fit(reset=True), orc.glacier_fit(reset=True)
+    assert np.array_equal(eg, eo, equal_nan=True), worst(eo, eg, "GMB_", 1e-300)[1]
+    sg, _ = gpu.get_state()
+    assert (sg[C["SD_GLAC_CUM_MASS_BALANCE"], isg] == 0).all()
+    # and end to end: the GPU's own accumulation over the same steps gives the same polynomial to 1e-6
+    gpu.set_state(sd0, si0)
+    gpu.push_forcing(f, sf, dmy)
+    gpu.dist_prec(0, nsteps)
+    eg2 = gpu.glacier_mass_balance_fit(reset=False)
+    orc.set_state(so, io)
+    eo2 = orc.glacier_fit(reset=False)
+    assert rel_diff(eg2[:3], eo2[:3], floor=1e-9).max() < 1e-5

@@ -159,3 +159,58 @@ def test_pure_functions_against_golden(oname, oracle_lib, ref_available):
             assert np.array_equal(ref.pure(fn, inp), exp, equal_nan=True), PURE_NAMES[fn]
     if ref is not None:
         ref.close()
+
+
+GMB_CASES = [("one_point", dict(FULL_ENERGY=1, Nband=3), True), ("two_points", dict(FULL_ENERGY=1, Nband=2), "all"),
+             ("quadratic_5_bands", dict(FULL_ENERGY=1, Nband=5), "all")]
+
+
+def _gmb_setup(kw, glacier, ncell=6, nsteps=72, doy=170):
+    opt = abi.default_options(**kw)
+    d = domain.make_domain(ncell, opt, ntile=2, glacier_top_band=glacier)
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
+    return d, f, sf, dmy
+
+
+@pytest.mark.parametrize("name,kw,glacier", GMB_CASES, ids=[c[0] for c in GMB_CASES])
+def test_glacier_mass_balance_fit_vs_reference(name, kw, glacier, oracle_lib, ref_available):
+    """End of a glacier accumulation interval (accumulateGlacierMassBalance.c:53-66): the per-cell quadratic fit of
+    accumulated mass balance against band elevation and the reset, oracle against the reference's own
+    GlacierMassBalanceResult / GraphingEquation -- bit for bit, for the 1-point, 2-point and least-squares branches
+    (two glacier HRUs at one elevation are merged into one point)."""
+    if not ref_available:
+        pytest.skip("reference build (oracle/_ref) not available")
+    d, f, sf, dmy = _gmb_setup(kw, glacier)
+    ref = oracle_lib.RefModel(d, "plain")
+    ref.init_state(f[0], dmy[0], d.init_moist)
+    sd0, si0 = ref.get_state()
+    isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+    sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0          # the accumulation window opens
+    ref.set_state(sd0, si0)
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    for s in range(f.shape[0]):
+        ref.step(f[s], sf[s], dmy[s]); orc.step(f[s], sf[s], dmy[s])
+    er, eo = ref.glacier_fit(reset=True), orc.glacier_fit(reset=True)
+    assert np.array_equal(er, eo, equal_nan=True), worst(er, eo, "GMB_", 1e-300)[1]
+    assert (eo[C["GMB_FIT_ERROR"]] >= 0).all() and np.abs(eo[C["GMB_B0"]]).max() > 0
+    if name == "quadratic_5_bands":
+        assert np.abs(eo[C["GMB_B2"]]).max() > 0
+    sr, _ = ref.get_state(); so, _ = orc.get_state()
+    assert np.array_equal(sr, so, equal_nan=True)
+    assert (so[C["SD_GLAC_CUM_MASS_BALANCE"], isg] == 0).all()
+    ref.close()
+
+
+@pytest.mark.parametrize("name,kw,glacier", GMB_CASES, ids=[c[0] for c in GMB_CASES])
+def test_glacier_mass_balance_fit_vs_golden(name, kw, glacier, oracle_lib):
+    """The same fit against the committed fixture (tests/golden/gmb_*.npz: the reference's state before the fit and the
+    reference's polynomial), for boxes without the reference."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gmb_%s.npz" % name))
+    d, f, sf, dmy = _gmb_setup(kw, glacier)
+    assert np.array_equal(d.cell_params, g["cell_params"], equal_nan=True) and np.array_equal(d.hru_iparams, g["hru_iparams"])
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(g["sd"], g["si"])
+    eo = orc.glacier_fit(reset=True)
+    assert np.array_equal(eo, g["eq"], equal_nan=True), worst(g["eq"], eo, "GMB_", 1e-300)[1]

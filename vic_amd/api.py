@@ -60,6 +60,7 @@ def load_library():
         "vicgpu_device_ptr": (vp, [vp, ctypes.c_int]),
         "vicgpu_last_kernel_ms": (ctypes.c_int, [vp, _dp, _ip]),
         "vicgpu_debug_pure": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
+        "vicgpu_glacier_mass_balance_fit": (ctypes.c_int, [vp, _dp, ctypes.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
@@ -76,6 +77,7 @@ EXPORTED_SYMBOLS = [
     "vicgpu_set_state", "vicgpu_get_state", "vicgpu_push_forcing", "vicgpu_step", "vicgpu_synchronize", "vicgpu_get_fluxes",
     "vicgpu_get_cell_outputs", "vicgpu_get_accum", "vicgpu_reset_accum", "vicgpu_get_cell_errors", "vicgpu_set_stream",
     "vicgpu_set_write_fluxes", "vicgpu_device_ptr", "vicgpu_last_kernel_ms", "vicgpu_debug_pure",
+    "vicgpu_glacier_mass_balance_fit",
 ]
 
 
@@ -181,6 +183,12 @@ class Model:
 
     def set_write_fluxes(self, on):
         self._chk(self.lib.vicgpu_set_write_fluxes(self.h, int(bool(on))))
+
+    def glacier_mass_balance_fit(self, reset=True):
+        """End of a glacier accumulation interval (accumulateGlacierMassBalance.c:53-66): [GMB_NROW][ncell] fit per cell."""
+        eq = np.zeros((C["GMB_NROW"], self.dom.ncell))
+        self._chk(self.lib.vicgpu_glacier_mass_balance_fit(self.h, _d(eq), int(bool(reset))))
+        return eq
 
     def debug_pure(self, fn, inputs):
         """Test hook (vicgpu_debug_pure): one pure function of the path for every row of inputs [n][VICGPU_PURE_NIN]."""

@@ -714,6 +714,84 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+// ------------------------------------------------------------------------------------------------ glacier mass-balance fit
+// GlacierMassBalanceResult.c:34-73 + GraphingEquation.c:8-125 for every cell at once (lane = cell): the accumulated
+// mass balance of the cell's glacier HRUs against band elevation, points merged per elevation in hruList order, closed-form
+// normal equations in the reference's order of operations; then resetAccumulationValues
+// (accumulateGlacierMassBalance.c:5-11) when asked.
+struct GArgs {
+  Opt o;
+  int ncell, nhru, reset;
+  const double* cell_params;
+  const int* cell_off;
+  const int* cell_list;
+  const int* hpi;
+  double* sd;
+  double* eq;          // [GMB_NROW][ncell]
+};
+
+__global__ __launch_bounds__(64) void vic_glacier_fit(const GArgs a) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= a.ncell) return;
+  const size_t nh = a.nhru, nc = a.ncell;
+  CellView cv{a.cell_params, a.ncell, c, a.o.Nnode, a.o.Nband};
+  double X[VIC_MAX_BANDS], Y[VIC_MAX_BANDS];      // at most one point per band elevation
+  int np = 0;
+  for (int k = a.cell_off[c]; k < a.cell_off[c + 1]; k++) {
+    const int g = a.cell_list[k];
+    if (a.hpi[(size_t)HPI_IS_GLACIER * nh + g] == 0) continue;
+    const double cum = a.sd[(size_t)SD_GLAC_CUM_MASS_BALANCE * nh + g];
+    if (!isnan(cum)) {
+      const double x = cv.band(CPB_BANDELEV, a.hpi[(size_t)HPI_BAND * nh + g]);
+      bool found = false;
+      for (int j = 0; j < np; j++)
+        if (X[j] == x) { Y[j] += cum; found = true; }
+      if (!found && np < VIC_MAX_BANDS) { X[np] = x; Y[np] = cum; np++; }
+    }
+    if (a.reset) a.sd[(size_t)SD_GLAC_CUM_MASS_BALANCE * nh + g] = 0.0;
+  }
+  int k2 = 0;
+  for (int i = 0; i < np; i++)
+    if (!(X[i] == 0)) { X[k2] = X[i]; Y[k2] = Y[i]; k2++; }       // "meaningless" points (GlacierMassBalanceResult.c:58-66)
+  np = k2;
+  double b0 = 0, b1 = 0, b2 = 0, fit = -1;
+  if (np == 1) b0 = Y[0];
+  else if (np == 2) {
+    const double slope = (Y[1] - Y[0]) / (X[1] - X[0]);
+    b0 = Y[0] - slope * X[0]; b1 = slope;
+  } else if (np >= 3) {
+    double sumx4 = 0, sumx3 = 0, sumx2 = 0, sumx1 = 0;
+    const int size = np;
+    for (int i = 0; i < np; i++) {
+      sumx4 += X[i] * X[i] * X[i] * X[i];
+      sumx3 += X[i] * X[i] * X[i];
+      sumx2 += X[i] * X[i];
+      sumx1 += X[i];
+    }
+    const double det = (sumx4 * sumx2 * size) + (sumx3 * sumx1 * sumx2) + (sumx2 * sumx3 * sumx1) - (sumx2 * sumx2 * sumx2)
+                       - (sumx1 * sumx1 * sumx4) - (size * sumx3 * sumx3);
+    const double inv[3][3] = {{size * sumx2 - sumx1 * sumx1, -(size * sumx3 - sumx1 * sumx2), sumx1 * sumx3 - sumx2 * sumx2},
+                              {-(size * sumx3 - sumx2 * sumx1), size * sumx4 - sumx2 * sumx2, -(sumx1 * sumx4 - sumx3 * sumx2)},
+                              {sumx1 * sumx3 - sumx2 * sumx2, -(sumx1 * sumx4 - sumx2 * sumx3), sumx2 * sumx4 - sumx3 * sumx3}};
+    double acoef[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < np; j++) {
+        const double stuff = inv[i][0] * (X[j] * X[j]) + inv[i][1] * X[j] + inv[i][2] * 1;
+        acoef[i] += stuff * Y[j];
+      }
+      acoef[i] /= det;
+    }
+    b0 = acoef[2]; b1 = acoef[1]; b2 = acoef[0];
+  }
+  if (np > 0) {
+    fit = 0;
+    for (int i = 0; i < np; i++) fit += fabs((b0 + b1 * X[i] + b2 * (X[i] * X[i])) - Y[i]);
+  }
+  a.eq[(size_t)GMB_B0 * nc + c] = b0; a.eq[(size_t)GMB_B1 * nc + c] = b1; a.eq[(size_t)GMB_B2 * nc + c] = b2;
+  a.eq[(size_t)GMB_FIT_ERROR * nc + c] = fit;
+}
+
 // ------------------------------------------------------------------------------------------------ test hook
 struct DArgs { Opt o; const double* cell_params; int ncell, fn, n; const double* in; double* out; };
 
@@ -1364,6 +1442,23 @@ int vicgpu_reset_accum(vicgpu_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemsetAsync(c->d_accum, 0, sizeof(double) * CA_NROW * c->ncell, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_cell_err, 0, sizeof(int) * c->ncell, c->stream));
+  return VICGPU_OK;
+}
+
+int vicgpu_glacier_mass_balance_fit(vicgpu_ctx* c, double* eq, int reset) {
+  if (!c || !c->d_cp || !eq) return VICGPU_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  double* d_eq = nullptr;
+  HIPCHK(c, hipMalloc(&d_eq, sizeof(double) * GMB_NROW * c->ncell));
+  GArgs g;
+  g.o = c->o; g.ncell = c->ncell; g.nhru = c->nhru; g.reset = reset ? 1 : 0; g.cell_params = c->d_cp; g.cell_off = c->d_cell_off;
+  g.cell_list = c->d_cell_list; g.hpi = c->d_hpi; g.sd = c->d_sd; g.eq = d_eq;
+  hipLaunchKernelGGL(vic_glacier_fit, dim3((c->ncell + 63) / 64), dim3(64), 0, c->stream, g);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(eq, d_eq, sizeof(double) * GMB_NROW * c->ncell, hipMemcpyDeviceToHost);
+  HIPIGN(hipFree(d_eq));
+  HIPCHK(c, e);
   return VICGPU_OK;
 }
 

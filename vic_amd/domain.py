@@ -353,7 +353,11 @@ def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, 
             slot = k * Nb + b
             g = slot * ncell + cells
             vidx = tile_classes[k]
-            if glacier_top_band and b == Nb - 1 and k == 0:
+            # glacier_top_band: True = tile 0 of the top band; "all" = tile 0 of every band (and tile 1 of the top band too:
+            # two glacier HRUs at one elevation, which GlacierMassBalanceResult.c:40-47 merges into one point)
+            if glacier_top_band and k == 0 and (b == Nb - 1 or glacier_top_band == "all"):
+                vidx = 2
+            if glacier_top_band == "all" and k == 1 and b == Nb - 1:
                 vidx = 2
             hpi[C["HPI_CELL"], g] = cells
             hpi[C["HPI_BAND"], g] = b
