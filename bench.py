@@ -163,6 +163,17 @@ def main():
     kernel_ms, nlaunch = m.last_kernel_ms()
     nerr = int((m.get_cell_errors() != 0).sum())
     acc = m.get_accum()
+    gather_ms = None
+    if use_dist:
+        # the one exchange of the path: the per-cell output table to the writer, RCCL all-gather over xGMI;
+        # outside the timed region (it happens once per output step, not per model step)
+        from vic_amd import shard
+        barrier()
+        tg = time.perf_counter()
+        full = shard.gather_cell_table(acc, [ncell] * world, device=torch.device("cuda", local_rank))
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        assert full.shape == (acc.shape[0], ncell * world)
 
     if rank == 0:
         hru_per_cell = d.nhru // d.ncell
@@ -175,7 +186,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["workload"], "cells_per_gpu": ncell, "hru_per_cell": hru_per_cell,
                        "parallelism": "cells sharded across %d GPU(s), no data-path collective" % world,
-                       "cells_with_error_flags": nerr,
+                       "cells_with_error_flags": nerr, "output_gather_ms": gather_ms,
                        "mean_runoff_mm_per_step": float(acc[C["CA_RUNOFF"]].mean() / max(1, K)),
                        "mean_swe_mm_end": float(acc[C["CA_SWE_END"]].mean())},
             # one "launch" of the hot path = one model step of the rank's cells: the QUICK_FLUX path is a single kernel, the
