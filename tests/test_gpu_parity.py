@@ -420,3 +420,34 @@ def test_glacier_mass_balance_fit(name, kw, glacier, oracle_lib):
     orc.set_state(so, io)
     eo2 = orc.glacier_fit(reset=False)
     assert rel_diff(eg2[:3], eo2[:3], floor=1e-9).max() < 1e-5
+
+
+def test_both_profile_kernels_agree(monkeypatch, oracle_lib):
+    """The soil-profile solve exists as a lock-step kernel (default) and as a flat per-lane state machine
+    (VICGPU_PROFILE_KERNEL=flat).  Per HRU both execute the reference's operation sequence, so their results are identical,
+    and both match the oracle."""
+    from vic_amd.api import Model
+    kw, ncell, ntile, doy = CASES["frozen_fixed"]
+    nsteps = 24
+    d, f, sf, dmy, sd0, si0 = _setup(kw, 96, ntile, nsteps, doy)
+    out = {}
+    for kern in ("lockstep", "flat"):
+        monkeypatch.setenv("VICGPU_PROFILE_KERNEL", kern)
+        m = Model(d)
+        m.set_state(sd0, si0)
+        m.push_forcing(f, sf, dmy)
+        m.dist_prec(0, nsteps)
+        out[kern] = m.get_state() + (m.get_fluxes(),)
+        assert m.get_cell_errors().sum() == 0
+        del m
+    for a, b in zip(out["lockstep"], out["flat"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    for s in range(nsteps):
+        orc.step(f[s], sf[s], dmy[s])
+    so, _ = orc.get_state()
+    sg = out["lockstep"][0].copy()
+    so[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
+    w, msg = worst(so, sg, "SD_", floor=1e-2)      # free-running: 1e-5 relative, 1e-7 absolute (near-zero ice at a thaw front)
+    assert w < FREE_TOL, msg

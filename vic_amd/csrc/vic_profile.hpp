@@ -233,4 +233,166 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
 #undef REC
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lock-step variant: with the work lists keyed by the frozen-node count, the 64 HRUs a wave takes together have their
+// Brent solves at the same nodes, so the reference's loop nest can run as written -- sweeps { nodes { Brent } } -- with the
+// wave iterating each node's Brent until its slowest lane is through.  Node temperatures stay in registers (the node
+// loop is unrolled), there is no per-lane mode, no gate and no LDS; the price is that every node and every sweep costs
+// the maximum over the wave.
+// ------------------------------------------------------------------------------------------------
+template <int NN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void vic_profile_solve_lockstep(const PArgs a) {
+  __shared__ int bcount[NBUCKET];
+  __shared__ double Tl[NN * 64];
+  __shared__ double T0l[NN * 64];
+  const int lane = threadIdx.x;
+#define T(j) Tl[(j) * 64 + lane]
+#define T0(j) T0l[(j) * 64 + lane]
+  for (int b = lane; b < NBUCKET; b += 64) bcount[b] = a.count[b];
+  if (blockIdx.x == 0) {
+    for (int b = lane; b < NBUCKET; b += 64) a.count_zero[b] = 0;
+    if (lane == 0) *a.evalonly_zero = 0;
+  }
+  __syncthreads();
+  int n = 0;
+#pragma unroll
+  for (int b = 0; b < NBUCKET; b++) n += bcount[b];
+  if ((int)blockIdx.x * 64 >= n) return;
+
+  const int Nn = (NN == VIC_MAX_NODES) ? a.Nn : NN;
+  const int jlast = a.NOFLUX ? Nn : Nn - 1;
+  const int MAXIT = 1000;
+  const double threshold = 1.e-2;
+  const bool EXP_TRANS = a.EXP_TRANS != 0;
+
+  while (true) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(a.next, 64);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= n) break;
+    const int slot = base + lane;
+    const bool have = slot < n;
+    int hru = 0, ps = 0;
+    const double* __restrict__ blk = a.pin;
+    bool frozen_on = false;
+    if (have) {
+      int rem = slot, found = 0;
+#pragma unroll 1
+      for (int b = NBUCKET - 1; b >= 0; b--) {
+        const int cb = bcount[b];
+        if (rem < cb) { found = b * a.cap + rem; break; }
+        rem -= cb;
+      }
+      hru = a.list[found];
+      blk = a.pin + (size_t)hru * Nn * PREC;
+      ps = a.pslot[hru];
+      frozen_on = blk[PR_A] != 0.0;
+      const double Ts = a.ts[hru];
+#pragma unroll
+      for (int k = 0; k < NN; k++)
+        if (k < Nn) { const double t = (k == 0) ? Ts : blk[k * PREC + PR_T0]; T0(k) = t; T(k) = t; }
+    }
+#define LS_REC() (a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn))
+#define LS_CNT(j) (reinterpret_cast<int*>(LS_REC() + Nn + 1)[j])
+    if (have) {
+#pragma unroll
+      for (int k = 0; k < NN; k++)
+        if (k < Nn) LS_CNT(k) = 0;
+    }
+    unsigned fbmask = 0;
+    bool ok = true, converged = (jlast <= 1);
+    bool sweeping = have && !converged;
+    int it = 1;
+    while (__any(sweeping)) {
+      double maxdiff = threshold;
+#pragma unroll 1
+      for (int j = 1; j < NN; j++) {
+        if (j < jlast) {
+          bool fz = false;
+          double oldT = 0, newT = 0;
+          BrentLean br;
+          SoilThermalEqn eq;
+          br.phase = BrentLean::DONE;
+          if (sweeping) {
+            oldT = T(j);
+            const double Tdn = (j == Nn - 1) ? oldT : T((j + 1 < NN) ? j + 1 : j), Tup = T(j - 1);
+            const double* __restrict__ r = blk + j * PREC;
+            const double A = r[PR_A], B = r[PR_B], C = r[PR_C], D = r[PR_D], T0j = T0(j);
+            if (oldT >= 0 || !frozen_on) {
+              const double EI = r[PR_EI];
+              if (!EXP_TRANS) newT = (A * T0j + B * (Tdn - Tup) + C * Tdn + D * Tup + EI) / (A + C + D);
+              else newT = (A * T0j + B * (Tdn - Tup) + C * (Tdn + Tup) - D * (Tdn - Tup) + EI) / (A + 2. * C);
+            } else {
+              eq.TL = Tdn; eq.TU = Tup; eq.T0 = T0j; eq.moist = r[PR_MOIST]; eq.ice0 = r[PR_ICE];
+              eq.A = A; eq.C = C; eq.D = D; eq.E = r[PR_E];
+              eq.max_moist = r[PR_MAXM];
+              eq.prepare(B, r[PR_BUB], r[PR_EXPT], j);
+              br.start(T0j - SOIL_DT, T0j + SOIL_DT);
+              fz = true;
+            }
+          }
+          while (__any(fz && !br.finished())) {
+            if (fz && !br.finished()) {
+              const double fx = eq.eval(br.x, EXP_TRANS);
+              br.advance(fx);
+            }
+          }
+          if (sweeping) {
+            if (fz) {
+              newT = br.b;
+              if (br.phase == BrentLean::FAILED) {
+                if (a.TFALLBACK) { newT = eq.T0; fbmask |= (1u << j); LS_CNT(j) += 1; }
+                else { ok = false; sweeping = false; }
+              }
+            }
+            if (sweeping) {
+              T(j) = newT;
+              const double diff = fabs(oldT - newT);
+              if (diff > maxdiff) maxdiff = diff;
+            }
+          }
+        }
+      }
+      if (sweeping) {                               // end of a Gauss-Seidel sweep (frozen_soil.c:466)
+        if (maxdiff <= threshold) { converged = true; sweeping = false; }
+        else if (it >= MAXIT) sweeping = false;
+        else it++;
+      }
+    }
+    if (have) {
+      if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T(j)); Tlast == T0
+#pragma unroll
+        for (int k = 1; k < NN - 1; k++) {
+          if (k < Nn - 1) {
+            const double Tk = T(k), Tm = T(k - 1), Tp = T(k + 1), Lk = T0(k), Lm = T0(k - 1), Lp = T0(k + 1);
+            if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
+              T(k) = 0.5 * (Tm + Tp);
+              fbmask |= (1u << k);
+              LS_CNT(k) += 1;
+            }
+          }
+        }
+      }
+      if (ok && !converged) {
+        if (a.TFALLBACK) {
+#pragma unroll
+          for (int k = 0; k < NN; k++)
+            if (k < Nn) { T(k) = T0(k); LS_CNT(k) += 1; }
+          fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
+        } else ok = false;
+      }
+      double* __restrict__ rec = LS_REC();
+#pragma unroll
+      for (int k = 0; k < NN; k++)
+        if (k < Nn) rec[k] = T(k);
+      rec[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
+      a.pout[(size_t)hru * pout_hru_stride(Nn) + pout_key(Nn, ps)] = T0(0);
+    }
+  }
+}
+#undef T
+#undef T0
+#undef LS_REC
+#undef LS_CNT
+
 }  // namespace vic

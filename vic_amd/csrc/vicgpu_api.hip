@@ -925,6 +925,7 @@ struct vicgpu_ctx {
   double *d_pin = nullptr, *d_ts = nullptr, *d_pout = nullptr;
   int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr;
   int profile_waves = 0;           // resident waves of the profile kernel
+  bool profile_lockstep = true;    // which of the two profile kernels (VICGPU_PROFILE_KERNEL=flat|lockstep)
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
 };
@@ -967,18 +968,21 @@ static hipError_t launch_fd_stage(const KArgs& ka, bool multi, hipStream_t st) {
 }
 
 template <int NN>
-static hipError_t launch_profile(const PArgs& pa, int nmax, int resident_waves, hipStream_t st) {
+static hipError_t launch_profile(const PArgs& pa, int nmax, int resident_waves, bool lockstep, hipStream_t st) {
   int nblk = (nmax + 63) / 64;
   if (nblk > resident_waves) nblk = resident_waves;      // persistent waves pull from the work list
   if (nblk < 1) nblk = 1;                                // block 0 also clears the counters of the round
-  hipLaunchKernelGGL((vic_profile_solve<NN>), dim3(nblk), dim3(64), 0, st, pa);
+  if (lockstep) hipLaunchKernelGGL((vic_profile_solve_lockstep<NN>), dim3(nblk), dim3(64), 0, st, pa);
+  else hipLaunchKernelGGL((vic_profile_solve<NN>), dim3(nblk), dim3(64), 0, st, pa);
   return hipGetLastError();
 }
 
 template <int NN>
-static int profile_resident_waves(int device) {
+static int profile_resident_waves(int device, bool lockstep) {
   int per_cu = 0, ncu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve<NN>, 64, 0) != hipSuccess || per_cu <= 0) per_cu = 8;
+  hipError_t e = lockstep ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve_lockstep<NN>, 64, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve<NN>, 64, 0);
+  if (e != hipSuccess || per_cu <= 0) per_cu = 8;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
   return per_cu * ncu;
 }
@@ -1032,7 +1036,8 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
     for (int round = 0;; round++) {
       pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur * NBUCKET; pa.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
       pa.evalonly_zero = ch->d_count + CNT_EVALONLY;
-      CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, st) : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, st)));
+      CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, c->profile_lockstep, st)
+                     : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, c->profile_lockstep, st)));
       ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1) * NBUCKET;
       hipLaunchKernelGGL(vic_surf_eval, dim3((ch->gcount + 63) / 64), dim3(64), 0, st, ea);
       CHKCH(ch, hipGetLastError());
@@ -1251,7 +1256,11 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
     HIPCHK(c, hipMemset(c->d_hstate, 0, sizeof(int) * nhru));
     HIPCHK(c, hipMemset(c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, hipMemset(c->d_pout, 0, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
-    c->profile_waves = (Nn == 10) ? profile_resident_waves<10>(c->device) : profile_resident_waves<VIC_MAX_NODES>(c->device);
+    // the profile kernel: lock-step over the keyed work lists by default, the flat per-lane state machine on request
+    c->profile_lockstep = true;
+    if (const char* ev = getenv("VICGPU_PROFILE_KERNEL")) c->profile_lockstep = (strcmp(ev, "flat") != 0);
+    c->profile_waves = (Nn == 10) ? profile_resident_waves<10>(c->device, c->profile_lockstep)
+                                  : profile_resident_waves<VIC_MAX_NODES>(c->device, c->profile_lockstep);
     // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  One chunk is the
     // default: the persistent profile kernel fills every SIMD, so concurrent chunks mostly queue behind each other.
     int nchunk = 1;
