@@ -615,15 +615,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       // spilled) across solve_snow
       load_node_props<NN>(a, g, w.nd);
       {
-        int nfrozen = 0, lo = 0, hi = 0;
+        int nfrozen = 0;
 #pragma unroll
         for (int n = 1; n < NN; n++)
-          if (n < Nn && eb.frozen_on && w.nd.T[n] < 0) { nfrozen++; if (lo == 0) lo = n; hi = n; }
-#ifdef PROFILE_KEY_PATTERN
-        key = (nfrozen == 0) ? 0 : 1 + ((lo - 1) * 17 + (hi - lo)) % (NBUCKET - 1);
-#else
-        key = nfrozen;
-#endif
+          if (n < Nn && eb.frozen_on && w.nd.T[n] < 0) nfrozen++;
+        key = nfrozen;       // finer keys (frozen range, thawed top) and the measured trip count were tried: no better
         a.hkey[g] = key;
       }
       profile_item_store<NN>(o, cv, s3, w.nd, eb.delta_t, eb.frozen_on != 0, a.pin + (size_t)g * Nn * PREC);
