@@ -8,7 +8,7 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
  *
  * Parity status: PINNED against the real reference compiled here
- * (oracle/ref_build/build_ref.sh -> oracle/_ref/libvicref*.so; tests/test_oracle_vs_ref.py)
+ * (oracle/ref_build/build_ref.sh -> oracle/_ref/libvicref*.so; tests/test_oracle.py)
  * and against committed golden vectors generated from that build (tests/golden/).
  * The reference itself ships no golden outputs (SURVEY.md Finding 3).
  *

@@ -1,7 +1,7 @@
 """ctypes wrappers around the checker libraries — TEST INFRASTRUCTURE ONLY.
 
 RefModel   -> oracle/_ref/libvicref*.so   (the real reference, built by oracle/ref_build/build_ref.sh)
-OracleModel-> oracle/libvicoracle.so       (the C restatement, oracle/vic_oracle*.c)
+OracleModel-> oracle/libvicoracle.so       (the C restatement, oracle/orc_*.c)
 
 Both expose the same small interface over the tables of include/vicgpu.h so that
 tests can drive reference, oracle and the HIP product with identical inputs.
