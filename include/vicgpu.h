@@ -90,7 +90,8 @@ typedef struct vicgpu_options {
   int frozen_compat;        /* 1 = reproduce frozen_soil.c:218-221 (layer arrays indexed by node,
                                SURVEY.md Finding 1.2); 0 = node arrays ("fixed") */
   int nveg_types;           /* veg_lib[0].NVegLibTypes; the table holds nveg_types + 4 rows */
-  int reserved_i[3];
+  int CORRPREC;             /* gauge-undercatch correction of precipitation (correct_precip.c, full_energy.c:188-194) */
+  int reserved_i[2];
   double wind_h;            /* global_param.wind_h (m) */
   double reserved_d[3];
 } vicgpu_options;

@@ -98,6 +98,7 @@ typedef struct {
          density[ORC_MAX_SUB], shortwave[ORC_MAX_SUB], longwave[ORC_MAX_SUB], wind[ORC_MAX_SUB];
   int snowflag[ORC_MAX_SUB];
   double out_prec, out_rain, out_snow;
+  double gauge_correction[2];   /* [0] rain, [1] snow: set by orc_full_energy (full_energy.c:188-194) */
 } orc_atmos;
 
 typedef struct { int month, day_in_year, hour, day, year; } orc_dmy;

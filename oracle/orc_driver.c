@@ -324,6 +324,15 @@ static int orc_surface_fluxes(const orc_model *m, orc_hru *h, const orc_soil *sc
 
 /* full_energy.c:8-498 for one cell (no lakes, no EXCESS_ICE) */
 int orc_full_energy(const orc_model *m, const orc_soil *sc, orc_atmos *atmos, const orc_dmy *dmy, orc_hru **hrus, int nhru) {
+  /* correct_precip.c:9-53, applied as in full_energy.c:188-194 */
+  atmos->gauge_correction[0] = 1; atmos->gauge_correction[1] = 1;
+  if (m->opt.CORRPREC && atmos->prec[m->NR] > 0) {
+    const double GAUGE_HEIGHT = 1.0;
+    double gauge_wind = atmos->wind[m->NR] * (log((GAUGE_HEIGHT + sc->rough) / sc->rough) / log(m->opt.wind_h / sc->rough));
+    atmos->gauge_correction[0] = 100. / exp(4.606 - 0.041 * pow(gauge_wind, 0.69));
+    gauge_wind = atmos->wind[m->NR] * (log((GAUGE_HEIGHT + sc->snow_rough) / sc->snow_rough) / log(m->opt.wind_h / sc->snow_rough));
+    atmos->gauge_correction[1] = 100. / exp(4.606 - 0.036 * pow(gauge_wind, 1.75));
+  }
   const int NR = m->NR, month = dmy->month;
   orc_vc displacement, roughness, ref_height, wind_speed, aero_resist[ORC_NPET + 1];
   int k, p, l;

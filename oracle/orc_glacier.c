@@ -504,8 +504,8 @@ int orc_surface_fluxes_glac(const orc_model *m, orc_hru *h, const orc_soil *sc, 
     Tair = atmos->air_temp[hidx] + sc->Tfactor[h->band];
     step_prec = atmos->prec[hidx] / 1.0 * sc->Pfactor[h->band];
     rainOnly = orc_calc_rainonly(m, Tair, step_prec, sc->MAX_SNOW_TEMP, sc->MIN_RAIN_TEMP);
-    snowfall = 1.0 * (step_prec - rainOnly) * sc->PADJ_S;
-    rainfall = 1.0 * rainOnly * sc->PADJ_R;
+    snowfall = atmos->gauge_correction[1] * (step_prec - rainOnly) * sc->PADJ_S;      /* surface_fluxes_glac.c:244-245 */
+    rainfall = atmos->gauge_correction[0] * rainOnly * sc->PADJ_R;
     step_out_prec = snowfall + rainfall;
     step_out_rain = rainfall;
     step_out_snow = snowfall;

@@ -695,8 +695,8 @@ double orc_solve_snow(const orc_model *m, int overstory, double BareAlbedo, doub
   *ppt = 0.;
   *melt_energy = 0.;
   rainonly = orc_calc_rainonly(m, air_temp, prec, sc->MAX_SNOW_TEMP, sc->MIN_RAIN_TEMP);
-  *snowfall = 1.0 * (prec - rainonly) * sc->PADJ_S;      /* gauge_correction[SNOW] = 1 (CORRPREC off, full_energy.c:191-194) */
-  *rainfall = 1.0 * rainonly * sc->PADJ_R;
+  *snowfall = atmos->gauge_correction[1] * (prec - rainonly) * sc->PADJ_S;      /* solve_snow.c:159-160 */
+  *rainfall = atmos->gauge_correction[0] * rainonly * sc->PADJ_R;
   *out_prec = *snowfall + *rainfall;
   *out_rain = *rainfall;
   *out_snow = *snowfall;

@@ -60,6 +60,7 @@ void *vicref_create(const vicgpu_options *opt) {
   s.options.FULL_ENERGY = opt->FULL_ENERGY;
   s.options.FROZEN_SOIL = opt->FROZEN_SOIL;
   s.options.QUICK_FLUX = opt->QUICK_FLUX;
+  s.options.CORRPREC = opt->CORRPREC;
   s.options.NOFLUX = opt->NOFLUX;
   s.options.EXP_TRANS = opt->EXP_TRANS;
   s.options.GRND_FLUX_TYPE = opt->GRND_FLUX_TYPE;

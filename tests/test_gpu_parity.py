@@ -53,6 +53,9 @@ CASES = {
     "glacier_summer": (dict(FULL_ENERGY=1, Nband=3, glacier=True), 32, 2, 190),
     "glacier_frozen": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=2, frozen_compat=0, glacier=True), 32, 2, 120),
     "glacier_daily": (dict(FULL_ENERGY=0, dt=24, snow_step=3, Nband=2, glacier=True), 32, 2, 100),
+    # gauge-undercatch correction of precipitation (correct_precip.c), ordinary and glacier HRUs
+    "corrprec": (dict(FULL_ENERGY=1, CORRPREC=1), 48, 3, 330),
+    "corrprec_glacier": (dict(FULL_ENERGY=1, Nband=3, CORRPREC=1, glacier=True), 32, 2, 120),
 }
 
 

@@ -45,6 +45,8 @@ SIDE_BY_SIDE = [
     ("glacier", dict(FULL_ENERGY=1, Nband=3), "plain", 6, 2, True, 500, 120),
     ("sntherm_sun1999", dict(FULL_ENERGY=1, SNOW_DENSITY=1, SNOW_ALBEDO=1), "plain", 6, 3, False, 300, 1),
     ("vic412_ar410", dict(FULL_ENERGY=1, TEMP_TH_TYPE=0, AERO_RESIST_CANSNOW=3), "plain", 6, 3, False, 300, 350),
+    ("corrprec", dict(FULL_ENERGY=1, CORRPREC=1), "plain", 6, 3, False, 300, 330),
+    ("corrprec_glacier", dict(FULL_ENERGY=1, Nband=3, CORRPREC=1), "plain", 6, 2, True, 200, 120),
 ]
 
 

@@ -240,8 +240,10 @@ VIC_DEV bool surface_fluxes_glac(const Opt& o, const CellView& cv, const VegLib&
     const double Tair = fc.v(VIC_F_AIR_TEMP, hidx) + cv.band(CPB_TFACTOR, band);
     const double step_prec = fc.v(VIC_F_PREC, hidx) / 1.0 * cv.band(CPB_PFACTOR, band);
     const double rainOnly = calc_rainonly(o, Tair, step_prec, cv.s(CP_MAX_SNOW_TEMP), cv.s(CP_MIN_RAIN_TEMP));
-    double snowfall = 1.0 * (step_prec - rainOnly) * cv.s(CP_PADJ_S);
-    double rainfall = 1.0 * rainOnly * cv.s(CP_PADJ_R);
+    double gc[2];
+    gauge_correction(o, cv, fc, gc);
+    double snowfall = gc[1] * (step_prec - rainOnly) * cv.s(CP_PADJ_S);
+    double rainfall = gc[0] * rainOnly * cv.s(CP_PADJ_R);
     const double step_out_prec = snowfall + rainfall, step_out_rain = rainfall, step_out_snow = snowfall;
     const double Tgrnd = GLAC_TEMP, VPDcanopy = 0.;
     snow.blowing_flux = 0.0;

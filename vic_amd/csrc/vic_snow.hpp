@@ -5,6 +5,20 @@
 namespace vic {
 
 // calc_rainonly.c:12-103 (mu == 1)
+// correct_precip.c:9-53 as full_energy.c:188-194 applies it: WMO catch-ratio factors for rain and snow from the wind at
+// gauge height, 1 when CORRPREC is off or the step is dry.  gc[0] rain, gc[1] snow.
+VIC_DEV void gauge_correction(const Opt& o, const CellView& cv, const Forcing& fc, double* gc) {
+  gc[0] = 1; gc[1] = 1;
+  if (o.CORRPREC && fc.v(VIC_F_PREC, o.NR) > 0) {
+    const double GAUGE_HEIGHT = 1.0;
+    const double wind = fc.v(VIC_F_WIND, o.NR), rough = cv.s(CP_ROUGH), snow_rough = cv.s(CP_SNOW_ROUGH);
+    double gauge_wind = wind * (log((GAUGE_HEIGHT + rough) / rough) / log(o.wind_h / rough));
+    gc[0] = 100. / exp(4.606 - 0.041 * pow(gauge_wind, 0.69));
+    gauge_wind = wind * (log((GAUGE_HEIGHT + snow_rough) / snow_rough) / log(o.wind_h / snow_rough));
+    gc[1] = 100. / exp(4.606 - 0.036 * pow(gauge_wind, 1.75));
+  }
+}
+
 VIC_DEV double calc_rainonly(const Opt& o, double air_temp, double prec, double MAX_SNOW_TEMP, double MIN_RAIN_TEMP) {
   const double MIN_PREC = 1.e-5;
   double rainonly = 0;

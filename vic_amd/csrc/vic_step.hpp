@@ -24,8 +24,10 @@ VIC_DEV SolveSnowOut solve_snow(const Opt& o, const CellView& cv, const VegLib& 
   r.NetLongSnow = 0.; r.NetShortGrnd = 0.; r.NetShortSnow = 0.;
   const int month = dmy.month;
   const double rainonly = calc_rainonly(o, air_temp, prec, cv.s(CP_MAX_SNOW_TEMP), cv.s(CP_MIN_RAIN_TEMP));
-  double snowfall = 1.0 * (prec - rainonly) * cv.s(CP_PADJ_S);     // gauge correction = 1 (CORRPREC off)
-  double rainfall = 1.0 * rainonly * cv.s(CP_PADJ_R);
+  double gc[2];
+  gauge_correction(o, cv, fc, gc);
+  double snowfall = gc[1] * (prec - rainonly) * cv.s(CP_PADJ_S);
+  double rainfall = gc[0] * rainonly * cv.s(CP_PADJ_R);
   r.out_prec = snowfall + rainfall; r.out_rain = rainfall; r.out_snow = snowfall;
   const double store_snowfall = snowfall;
   r.Le = (2.501e6 - 0.002361e6 * air_temp);

@@ -1144,7 +1144,7 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   o.EXP_TRANS = opt->EXP_TRANS; o.GRND_FLUX_TYPE = opt->GRND_FLUX_TYPE; o.TFALLBACK = opt->TFALLBACK;
   o.AERO_RESIST_CANSNOW = opt->AERO_RESIST_CANSNOW; o.SNOW_ALBEDO = opt->SNOW_ALBEDO; o.SNOW_DENSITY = opt->SNOW_DENSITY;
   o.TEMP_TH_TYPE = opt->TEMP_TH_TYPE; o.GLACIER_ID = opt->GLACIER_ID; o.GLACIER_DYNAMICS = opt->GLACIER_DYNAMICS;
-  o.frozen_compat = opt->frozen_compat; o.nveg_types = opt->nveg_types; o.wind_h = opt->wind_h;
+  o.frozen_compat = opt->frozen_compat; o.nveg_types = opt->nveg_types; o.wind_h = opt->wind_h; o.CORRPREC = opt->CORRPREC;
   if (hipSetDevice(device) != hipSuccess) { delete c; return VICGPU_ERR_HIP; }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess
