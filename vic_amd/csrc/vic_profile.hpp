@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
 // the maximum over the wave.
 // ------------------------------------------------------------------------------------------------
 template <int NN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void vic_profile_solve_lockstep(const PArgs a) {
+__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_lockstep(const PArgs a) {
   __shared__ int bcount[NBUCKET];
   __shared__ double Tl[NN * 64];
   __shared__ double T0l[NN * 64];

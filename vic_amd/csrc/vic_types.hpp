@@ -13,6 +13,11 @@
 
 #define VIC_DEV __device__ __forceinline__
 #define VIC_DEVN __device__ __forceinline__
+#ifdef VIC_HOSTEMU   // sanitizer build for the host, tools/hostemu
+#define VIC_WAVES_PER_EU(lo, hi)
+#else
+#define VIC_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
 
 namespace vic {
 

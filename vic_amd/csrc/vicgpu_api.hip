@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
 // FIRST: the phase-0 instantiation; MULTI: the run has more than one snow sub-step per step (otherwise phase 1 never sets up
 // another sub-step and that code is not instantiated).
 template <int NN, bool FIRST, bool MULTI>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void vic_fd_stage(const KArgs a) {
+__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const KArgs a) {
   const int gi = blockIdx.x * 64 + threadIdx.x;
   if (gi >= a.gcount) return;
   const int g = a.glist ? a.glist[gi] : gi;
@@ -667,7 +667,7 @@ struct EArgs {
   int* evalonly;         // HRUs that wait for an evaluation without a solve (final evaluation on record)
 };
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void vic_surf_eval(const EArgs a) {
+__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const EArgs a) {
   const int gi = blockIdx.x * 64 + threadIdx.x;
   if (gi == 0) *a.profile_next = 0;
   if (gi >= a.gcount) return;
