@@ -18,7 +18,10 @@ CYC = {0: "stage / monolithic kernel total", 1: "load + prepare + aero", 2: "sol
        23: "profile kernel: Brent step", 24: "profile kernel: node finish + loop"}
 CNT = {0: "waves (stage launches)", 1: "lanes", 2: "sub-steps (wave)",
        7: "SurfEB evals (wave)", 8: "SurfEB evals (lane)", 9: "SnowPackEB evals (wave)", 10: "SnowPackEB evals (lane)",
-       11: "CanopyEB evals (wave)", 12: "CanopyEB evals (lane)"}
+       11: "CanopyEB evals (wave)", 12: "CanopyEB evals (lane)",
+       16: "lock-step: sweeps (wave)", 17: "lock-step: sweeps (lane)", 18: "lock-step: node visits (wave)",
+       19: "lock-step: frozen-node visits (lane)", 22: "lock-step: node visits with a Brent (wave)",
+       20: "lock-step: Brent iterations (wave)", 21: "lock-step: Brent iterations (lane)"}
 
 
 def main():

@@ -57,7 +57,11 @@ __host__ __device__ inline int pout_key(int Nn, int slot) { return 2 * pout_stri
 #ifndef PROFILE_GATE_LANES
 #define PROFILE_GATE_LANES 16
 #endif
-constexpr int PROFILE_GATE = PROFILE_GATE_LANES;     // lanes that must be waiting before the write-back / fetch section runs
+constexpr int PROFILE_GATE = PROFILE_GATE_LANES;
+#ifndef LOCKSTEP_GATE_LANES
+#define LOCKSTEP_GATE_LANES 16
+#endif
+constexpr int LOCKSTEP_GATE = LOCKSTEP_GATE_LANES;   // same for the lock-step kernel's refill of lanes whose item is through     // lanes that must be waiting before the write-back / fetch section runs
 
 template <int NN>
 __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
@@ -234,11 +238,12 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lock-step variant: with the work lists keyed by the frozen-node count, the 64 HRUs a wave takes together have their
-// Brent solves at the same nodes, so the reference's loop nest can run as written -- sweeps { nodes { Brent } } -- with the
-// wave iterating each node's Brent until its slowest lane is through.  Node temperatures stay in registers (the node
-// loop is unrolled), there is no per-lane mode, no gate and no LDS; the price is that every node and every sweep costs
-// the maximum over the wave.
+// Lock-step variant: with the work lists keyed by the frozen-node count, the 64 HRUs a wave holds have their Brent solves
+// at the same nodes, so the reference's loop nest can run as written -- sweeps { nodes { Brent } } -- with the wave
+// iterating each node's Brent until its slowest lane is through.  Node columns live in LDS, there is no per-lane mode
+// inside a sweep; a lane whose Gauss-Seidel iteration has ended writes its record and takes the next item at the gate
+// before the following sweep, so the sweep count is per lane (91 % of lanes busy per sweep) while every node visit still
+// costs the slowest lane's Brent (12.8 wave iterations for 8.2 per lane on cfg3: the 53 % lane utilisation that is left).
 // ------------------------------------------------------------------------------------------------
 template <int NN>
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_lockstep(const PArgs a) {
@@ -265,46 +270,49 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_l
   const double threshold = 1.e-2;
   const bool EXP_TRANS = a.EXP_TRANS != 0;
 
-  while (true) {
-    int base = 0;
-    if (lane == 0) base = atomicAdd(a.next, 64);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base >= n) break;
-    const int slot = base + lane;
-    const bool have = slot < n;
-    int hru = 0, ps = 0;
-    const double* __restrict__ blk = a.pin;
-    bool frozen_on = false;
-    if (have) {
-      int rem = slot, found = 0;
-#pragma unroll 1
-      for (int b = NBUCKET - 1; b >= 0; b--) {
-        const int cb = bcount[b];
-        if (rem < cb) { found = b * a.cap + rem; break; }
-        rem -= cb;
-      }
-      hru = a.list[found];
-      blk = a.pin + (size_t)hru * Nn * PREC;
-      ps = a.pslot[hru];
-      frozen_on = blk[PR_A] != 0.0;
-      const double Ts = a.ts[hru];
-#pragma unroll
-      for (int k = 0; k < NN; k++)
-        if (k < Nn) { const double t = (k == 0) ? Ts : blk[k * PREC + PR_T0]; T0(k) = t; T(k) = t; }
-    }
 #define LS_REC() (a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn))
 #define LS_CNT(j) (reinterpret_cast<int*>(LS_REC() + Nn + 1)[j])
-    if (have) {
+  // Per-lane item state.  A lane keeps its item across sweeps; when the item's Gauss-Seidel iteration ends the lane writes
+  // the record back and waits at the gate for the next item, so a wave is not held to its slowest HRU's sweep count.
+  bool have = false, sweeping = false, converged = false, ok = true, frozen_on = false;
+  int hru = 0, ps = 0, it = 1;
+  unsigned fbmask = 0;
+  const double* __restrict__ blk = a.pin;
+  bool more = true;                                  // wave-uniform: the work list has items nobody has taken yet
+  while (true) {
+    const unsigned long long idle = __ballot(!have);
+    if (more && (__popcll(idle) >= LOCKSTEP_GATE || idle == ~0ull)) {
+      const int nidle = __popcll(idle), leader = __ffsll((long long)idle) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(a.next, nidle);
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (base + nidle >= n) more = false;
+      const int slot = base + __popcll(idle & ((1ull << lane) - 1ull));
+      if (!have && slot < n) {
+        int rem = slot, found = 0;
+#pragma unroll 1
+        for (int b = NBUCKET - 1; b >= 0; b--) {
+          const int cb = bcount[b];
+          if (rem < cb) { found = b * a.cap + rem; break; }
+          rem -= cb;
+        }
+        hru = a.list[found];
+        blk = a.pin + (size_t)hru * Nn * PREC;
+        ps = a.pslot[hru];
+        frozen_on = blk[PR_A] != 0.0;
+        const double Ts = a.ts[hru];
 #pragma unroll
-      for (int k = 0; k < NN; k++)
-        if (k < Nn) LS_CNT(k) = 0;
+        for (int k = 0; k < NN; k++)
+          if (k < Nn) { const double t = (k == 0) ? Ts : blk[k * PREC + PR_T0]; T0(k) = t; T(k) = t; LS_CNT(k) = 0; }
+        have = true; fbmask = 0; ok = true; it = 1;
+        converged = (jlast <= 1);
+        sweeping = !converged;
+      }
     }
-    unsigned fbmask = 0;
-    bool ok = true, converged = (jlast <= 1);
-    bool sweeping = have && !converged;
-    int it = 1;
-    while (__any(sweeping)) {
+    if (!__any(have)) break;
+    {
       double maxdiff = threshold;
+      PROF_WAVE(16); PROF_VOTE(17, sweeping);
 #pragma unroll 1
       for (int j = 1; j < NN; j++) {
         if (j < jlast) {
@@ -331,7 +339,9 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_l
               fz = true;
             }
           }
+          PROF_WAVE(18); PROF_VOTE(19, fz); if (__any(fz)) PROF_WAVE(22);
           while (__any(fz && !br.finished())) {
+            PROF_WAVE(20); PROF_VOTE(21, fz && !br.finished());
             if (fz && !br.finished()) {
               const double fx = eq.eval(br.x, EXP_TRANS);
               br.advance(fx);
@@ -358,8 +368,8 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_l
         else if (it >= MAXIT) sweeping = false;
         else it++;
       }
-    }
-    if (have) {
+        }
+    if (have && !sweeping) {                        // this lane's item is through: finish it and free the lane
       if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T(j)); Tlast == T0
 #pragma unroll
         for (int k = 1; k < NN - 1; k++) {
@@ -387,6 +397,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_l
         if (k < Nn) rec[k] = T(k);
       rec[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
       a.pout[(size_t)hru * pout_hru_stride(Nn) + pout_key(Nn, ps)] = T0(0);
+      have = false;
     }
   }
 }
