@@ -23,12 +23,13 @@
 
 namespace vic {
 
-// Work lists are kept in NBUCKET segments by a per-HRU key (the number of frozen nodes at the start of the step): the
+// Work lists are kept in NBUCKET segments by a per-HRU key (the number of frozen nodes at the start of the step, and
+// whether a node sits within SOIL_DT of 0 C -- see vic_fd_stage): the
 // profile kernel takes the segments one after the other, most expensive first, so that the HRUs a wave works on at any time
 // have the same nodes in Brent solves and need about the same number of trips -- measured on the bench workload, waves
 // of identical HRUs run the whole step 36 % faster than waves of neighbouring cells (tools/exp/homogeneous.py).
 #ifndef PROFILE_NBUCKET
-#define PROFILE_NBUCKET (VIC_MAX_NODES + 2)
+#define PROFILE_NBUCKET (2 * (VIC_MAX_NODES + 2))
 #endif
 constexpr int NBUCKET = PROFILE_NBUCKET;
 
@@ -245,6 +246,14 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
 // before the following sweep, so the sweep count is per lane (91 % of lanes busy per sweep) while every node visit still
 // costs the slowest lane's Brent (12.8 wave iterations for 8.2 per lane on cfg3: the 53 % lane utilisation that is left).
 // ------------------------------------------------------------------------------------------------
+// tools/hostemu with -DVIC_HOSTEMU_HIST: histogram of Brent evaluations per node solve, split by whether the bracket
+// T0 +- SOIL_DT contains 0 C (how the work-list key of vic_fd_stage was chosen)
+#ifdef VIC_HOSTEMU_HIST
+static long vic_hist[64];
+static long vic_hist2[64];
+static void vic_hist_print() { for (int i = 0; i < 32; i++) printf("nit %d far %ld near %ld\n", i, vic_hist[i], vic_hist2[i]); }
+static void vic_hist_add(int n, bool near0) { static bool reg = (atexit(vic_hist_print), true); (void)reg; (near0 ? vic_hist2 : vic_hist)[n < 63 ? n : 63]++; }
+#endif
 template <int NN>
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_lockstep(const PArgs a) {
   __shared__ int bcount[NBUCKET];
@@ -278,6 +287,9 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_l
   int hru = 0, ps = 0, it = 1;
   unsigned fbmask = 0;
   const double* __restrict__ blk = a.pin;
+#ifdef VIC_HOSTEMU_HIST
+  int hist_nit = 0;
+#endif
   bool more = true;                                  // wave-uniform: the work list has items nobody has taken yet
   while (true) {
     const unsigned long long idle = __ballot(!have);
@@ -342,11 +354,17 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_l
           PROF_WAVE(18); PROF_VOTE(19, fz); if (__any(fz)) PROF_WAVE(22);
           while (__any(fz && !br.finished())) {
             PROF_WAVE(20); PROF_VOTE(21, fz && !br.finished());
+#ifdef VIC_HOSTEMU_HIST
+            if (fz && !br.finished()) hist_nit++;
+#endif
             if (fz && !br.finished()) {
               const double fx = eq.eval(br.x, EXP_TRANS);
               br.advance(fx);
             }
           }
+#ifdef VIC_HOSTEMU_HIST
+          if (fz) { vic_hist_add(hist_nit, fabs(eq.T0) < SOIL_DT); hist_nit = 0; }
+#endif
           if (sweeping) {
             if (fz) {
               newT = br.b;
