@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the VIC hot path (dist_prec -> full_energy -> surface_fluxes) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg2]
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg4|cfg2]
 
 A "step" is one model time step of every cell of the rank's shard (all HRUs, all snow sub-steps).
 Metric: cell-timesteps/s, whole job (sum over ranks).  Weak scaling: every rank owns a full copy of the
@@ -10,6 +10,7 @@ per-GPU workload (cells shard trivially, no data-path collective; BASELINE.json 
 Workloads (BASELINE.json configs, SURVEY.md 8(d) synthetic inputs):
   cfg3  100k cells, FULL_ENERGY + FROZEN_SOIL (10 thermal nodes, explicit, "fixed" node-parameter semantics),
         5 snow bands x 5 veg tiles = 25 HRUs/cell, hourly  -- the config the metric is quoted on (default)
+  cfg4  one GPU's share (125k cells) of the 1M-cell glacier config: cfg3 with veg slot 0 of the top band a glacier HRU
   cfg2  10k cells, FULL_ENERGY (QUICK_FLUX), 1 band x 3 veg tiles, hourly
 
 Forcing for all W+K steps is generated on the host and is resident in HBM before the timed region starts.
@@ -35,6 +36,11 @@ def config(name):
         opt = abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5, frozen_compat=0)
         return dict(opt=opt, ncell=100000, ntile=5, start_doy=60,
                     workload="cfg3: 100k cells, FULL_ENERGY+FROZEN_SOIL (Nnode=10, explicit, fixed), 5 bands x 5 veg tiles, hourly")
+    if name == "cfg4":       # one GPU's share of BASELINE.json configs[3] (1M cells on 8 GPUs): cfg3 + a glacier HRU in the top band
+        opt = abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5, frozen_compat=0)
+        return dict(opt=opt, ncell=125000, ntile=5, start_doy=60, glacier=True,
+                    workload="cfg4 share: 125k cells (1M / 8 GPUs), FULL_ENERGY+FROZEN_SOIL (Nnode=10, explicit, fixed), 5 bands x 5 veg tiles, "
+                             "veg slot 0 of the top band = glacier (solve_glacier / surface_fluxes_glac), hourly")
     if name == "cfg2":
         opt = abi.default_options(FULL_ENERGY=1)
         return dict(opt=opt, ncell=10000, ntile=3, start_doy=60,
@@ -60,7 +66,7 @@ def cpu_baseline(cfg, target_seconds=15.0):
     kind = "reference" if pyref.have_ref(variant) else "port"
 
     def run(ncell_s, nsteps):
-        d = domain.make_domain(ncell_s, copy.copy(opt), ntile=cfg["ntile"])
+        d = domain.make_domain(ncell_s, copy.copy(opt), ntile=cfg["ntile"], glacier_top_band=cfg.get("glacier", False))
         f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=cfg["start_doy"])
         sd0, si0 = init_state.initial_state(d, f[0])
         m = pyref.RefModel(d, variant) if kind == "reference" else pyref.OracleModel(d)
@@ -131,7 +137,7 @@ def main():
     ncell = args.ncell or cfg["ncell"]
     K, W = args.steps, args.warmup
     # every rank builds its own shard: a different seed = different cells, same statistics (cells never interact)
-    d = domain.make_domain(ncell, opt, ntile=cfg["ntile"], seed=domain.SEED + rank)
+    d = domain.make_domain(ncell, opt, ntile=cfg["ntile"], glacier_top_band=cfg.get("glacier", False), seed=domain.SEED + rank)
     f, sf, dmy = domain.make_forcing(d, 0, W + K, start_doy=cfg["start_doy"])
     sd0, si0 = init_state.initial_state(d, f[0])
     m = Model(d, device=local_rank)
