@@ -189,21 +189,26 @@ def test_chunking_is_invisible(monkeypatch):
         assert np.array_equal(a, b, equal_nan=True)
 
 
-def _cfg3(ncell, nsteps):
-    """The bench workload (bench.py cfg3 = BASELINE.json configs[2]): FULL_ENERGY + FROZEN_SOIL, 10 nodes, 5 bands x 5 tiles."""
+def _cfg3(ncell, nsteps, name="cfg3"):
+    """The bench workloads as bench.py builds them: cfg3 = BASELINE.json configs[2] (FULL_ENERGY + FROZEN_SOIL, 10 nodes,
+    5 bands x 5 tiles), cfg4 = one GPU's share of configs[3] (cfg3 + a glacier HRU in the top band of every cell)."""
     import bench
-    cfg = bench.config("cfg3")
-    d = domain.make_domain(ncell, cfg["opt"], ntile=cfg["ntile"])
+    cfg = bench.config(name)
+    d = domain.make_domain(ncell, cfg["opt"], ntile=cfg["ntile"], glacier_top_band=cfg.get("glacier", False))
     f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=cfg["start_doy"])
     sd0, si0 = init_state.initial_state(d, f[0])
+    if cfg.get("glacier"):
+        isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+        sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
     return d, f, sf, dmy, sd0, si0
 
 
-def test_bench_workload_against_oracle(oracle_lib):
-    """cfg3 exactly as bench.py builds it, at a size the oracle finishes in seconds, free-running for a day."""
+@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
+def test_bench_workload_against_oracle(name, oracle_lib):
+    """cfg3 / cfg4 exactly as bench.py builds them, at a size the oracle finishes in seconds, free-running for a day."""
     from vic_amd.api import Model
     nsteps = 24
-    d, f, sf, dmy, sd0, si0 = _cfg3(48, nsteps)
+    d, f, sf, dmy, sd0, si0 = _cfg3(48, nsteps, name)
     orc = oracle_lib.OracleModel(d)
     orc.set_state(sd0, si0)
     gpu = Model(d)
