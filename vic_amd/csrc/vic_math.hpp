@@ -200,7 +200,8 @@ struct Brent {
 // root_brent for a residual that never returns the -999 error sentinel (the frozen-node residual, soil_thermal_eqn.c,
 // has no error return): the bisection searches toward a valid side (root_brent.c:129-177, 192-238) are unreachable, so
 // the state is a, b, c, d, e, fa, fb, fc and three counters, and one step is branch-light.  Where the reference would
-// misread a residual of exactly -999.0 as an error flag this treats it as the number it is.  Same operations otherwise.
+// misread a residual of exactly -999.0 as an error flag this treats it as the number it is.  Same operations otherwise,
+// except the quotients of the interpolation step (below).
 struct BrentLean {
   enum Phase : int { EVAL_A0, EVAL_B0, EXP_A, EXP_B, MAIN, DONE, FAILED };      // DONE: the root is b
   double a, b, c, d, e, fa, fb, fc, x;
@@ -245,7 +246,14 @@ struct BrentLean {
     const double m = 0.5 * (c - b);
     if (fabs(m) <= tol || fb == 0) { phase = DONE; return; }
     const bool bisect = fabs(e) < tol || fabs(fa) <= fabs(fb);
+#ifdef VIC_REFERENCE_DIVISIONS
     const double s = fb / fa, q1 = fa / fc, r = fb / fc;
+#else
+    // the three quotients of the interpolation step from two reciprocals: the step only proposes the next trial point,
+    // the bracket logic and the stopping test are untouched (-4 % step time together with SoilThermalEqn::eval)
+    const double rfa = 1.0 / fa, rfc = 1.0 / fc;
+    const double s = fb * rfa, q1 = fa * rfc, r = fb * rfc;
+#endif
     const bool secant = (a == c);
     double p = secant ? 2 * m * s : s * (2 * m * q1 * (q1 - r) - (b - a) * (r - 1));
     double q = secant ? 1 - s : (q1 - 1) * (r - 1) * (s - 1);

@@ -17,7 +17,8 @@
 //   * node temperatures (the only per-lane-indexed data that changes) live in LDS as [node][lane]; the constant
 //     per-node records are read from the item block (vic_surface.hpp) when a lane enters a node.
 //
-// Per lane the sequence of floating-point operations, and therefore the result, is the reference's.
+// Per lane the sequence of floating-point operations is the reference's, up to the three last-bit exceptions listed at
+// SoilThermalEqn (vic_surface.hpp) and BrentLean (vic_math.hpp).
 #pragma once
 #include "vic_surface.hpp"
 

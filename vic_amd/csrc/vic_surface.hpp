@@ -15,14 +15,19 @@ VIC_DEV double estimate_T1(double Ts, double T1_old, double T2, double D1, doubl
 }
 
 // residual of one frozen node (soil_thermal_eqn.c:8-131).  prepare() hoists what does not depend on the trial
-// temperature out of the Brent iteration (same operations, same bits): the divisor and exponent of the
-// freezing-point-depression curve (maximum_unfrozen_water), B*(TL-TU) and the |TL-TU| > 5 test of the node-1 special case.
+// temperature out of the Brent iteration: the divisor and exponent of the freezing-point-depression curve
+// (maximum_unfrozen_water), B*(TL-TU) and the |TL-TU| > 5 test of the node-1 special case.  The argument of the curve,
+// -Lf*T/273.16/den in the reference, is formed with the reciprocal of 273.16*den (two fp64 divisions less per evaluation,
+// last-bit differences in an argument whose power already differs from glibc's pow in the last bits);
+// -DVIC_REFERENCE_DIVISIONS restores the reference's two divisions here and its three quotients in BrentLean.
 struct SoilThermalEqn {
   double TL, TU, T0, moist, max_moist, ice0, A, C, D, E;
   double den, yexp, flux_term1;
+  double inv_den;
   int steep;
   VIC_DEV void prepare(double B, double bubble, double expt, int node) {
     den = 9.81 * bubble / 100.;
+    inv_den = 1.0 / (273.16 * den);
     yexp = -(2.0 / (expt - 3.0));
     flux_term1 = B * (TL - TU);
     steep = (node == 1 && fabs(TL - TU) > 5.) ? 1 : 0;
@@ -30,7 +35,11 @@ struct SoilThermalEqn {
   VIC_DEV double eval(double T, bool EXP_TRANS) const {
     double ice;
     if (T < 0.) {
+#ifdef VIC_REFERENCE_DIVISIONS
       double u = max_moist * pow_pos((-LF * T) / 273.16 / den, yexp);       // maximum_unfrozen_water, T <= 0 branch
+#else
+      double u = max_moist * pow_pos((-LF * T) * inv_den, yexp);            // one rounding instead of two: see above
+#endif
       if (u > max_moist) u = max_moist;
       if (u < 0) u = 0;
       ice = moist - u;
