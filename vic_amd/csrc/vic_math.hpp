@@ -248,15 +248,19 @@ struct BrentLean {
     const bool bisect = fabs(e) < tol || fabs(fa) <= fabs(fb);
 #ifdef VIC_REFERENCE_DIVISIONS
     const double s = fb / fa, q1 = fa / fc, r = fb / fc;
-#else
-    // the three quotients of the interpolation step from two reciprocals: the step only proposes the next trial point,
-    // the bracket logic and the stopping test are untouched (-4 % step time together with SoilThermalEqn::eval)
-    const double rfa = 1.0 / fa, rfc = 1.0 / fc;
-    const double s = fb * rfa, q1 = fa * rfc, r = fb * rfc;
-#endif
     const bool secant = (a == c);
     double p = secant ? 2 * m * s : s * (2 * m * q1 * (q1 - r) - (b - a) * (r - 1));
     double q = secant ? 1 - s : (q1 - 1) * (r - 1) * (s - 1);
+#else
+    // The interpolation step p/q with s = fb/fa, q1 = fa/fc, r = fb/fc written over a common denominator: p and q are the
+    // reference's multiplied by fa (secant) or fa*fc^2 (inverse quadratic), which leaves the sign normalisation, the two
+    // acceptance tests (both homogeneous in p, q) and the quotient unchanged and needs one division instead of four.
+    // The step only proposes the next trial point; bracket logic and stopping test are untouched (-4 % step time
+    // together with SoilThermalEqn::eval).
+    const bool secant = (a == c);
+    double p = secant ? 2 * m * fb : fb * (2 * m * fa * (fa - fb) - (b - a) * (fb - fc) * fc);
+    double q = secant ? fa - fb : (fa - fc) * (fb - fc) * (fb - fa);
+#endif
     const bool ppos = p > 0;
     q = ppos ? -q : q;
     p = ppos ? p : -p;
