@@ -445,6 +445,9 @@ VIC_DEV double pow_pos(double x, double y) {
   if (!(x > 0.0 && x < 1.0e300)) return pow(x, y);   // 0, negative, inf, NaN: the library's corner cases
   return exp(y * ln_pos(x));
 }
+// For callers that guarantee a finite x > 0 (SoilThermalEqn::eval: x = -Lf*T*const with T < 0): no library fallback in the
+// Brent loop's code.
+VIC_DEV double pow_pos_finite(double x, double y) { return exp(y * ln_pos(x)); }
 
 VIC_DEV double maximum_unfrozen_water(double T, double max_moist, double bubble, double expt) {
   double u;

@@ -255,8 +255,11 @@ static long vic_hist2[64];
 static void vic_hist_print() { for (int i = 0; i < 32; i++) printf("nit %d far %ld near %ld\n", i, vic_hist[i], vic_hist2[i]); }
 static void vic_hist_add(int n, bool near0) { static bool reg = (atexit(vic_hist_print), true); (void)reg; (near0 ? vic_hist2 : vic_hist)[n < 63 ? n : 63]++; }
 #endif
+#ifndef LS_WAVES
+#define LS_WAVES 3      // 136 VGPRs; 4 waves/SIMD (128 VGPRs, 44 B scratch, LDS then allows 15 waves per CU) measured 1.5 % slower
+#endif
 template <int NN>
-__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(3, 3) void vic_profile_solve_lockstep(const PArgs a) {
+__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_profile_solve_lockstep(const PArgs a) {
   __shared__ int bcount[NBUCKET];
   __shared__ double Tl[NN * 64];
   __shared__ double T0l[NN * 64];

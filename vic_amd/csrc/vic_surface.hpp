@@ -38,7 +38,7 @@ struct SoilThermalEqn {
 #ifdef VIC_REFERENCE_DIVISIONS
       double u = max_moist * pow_pos((-LF * T) / 273.16 / den, yexp);       // maximum_unfrozen_water, T <= 0 branch
 #else
-      double u = max_moist * pow_pos((-LF * T) * inv_den, yexp);            // one rounding instead of two: see above
+      double u = max_moist * pow_pos_finite((-LF * T) * inv_den, yexp);     // one rounding instead of two: see above
 #endif
       if (u > max_moist) u = max_moist;
       if (u < 0) u = 0;
