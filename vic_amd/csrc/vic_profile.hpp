@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
         eq.TL = Tdn; eq.TU = Tup; eq.T0 = T0j; eq.moist = r[PR_MOIST]; eq.ice0 = r[PR_ICE];
         eq.A = A; eq.C = C; eq.D = D; eq.E = r[PR_E];
         eq.max_moist = r[PR_MAXM];
-        eq.prepare(B, r[PR_BUB], r[PR_EXPT], j);
+        eq.prepare(B, r[PR_CURVE_DIV], r[PR_CURVE_EXP], j);
         br.start(T0j - SOIL_DT, T0j + SOIL_DT);
         mode = BRENT;
       }
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
               eq.TL = Tdn; eq.TU = Tup; eq.T0 = T0j; eq.moist = r[PR_MOIST]; eq.ice0 = r[PR_ICE];
               eq.A = A; eq.C = C; eq.D = D; eq.E = r[PR_E];
               eq.max_moist = r[PR_MAXM];
-              eq.prepare(B, r[PR_BUB], r[PR_EXPT], j);
+              eq.prepare(B, r[PR_CURVE_DIV], r[PR_CURVE_EXP], j);
               br.start(T0j - SOIL_DT, T0j + SOIL_DT);
               fz = true;
             }

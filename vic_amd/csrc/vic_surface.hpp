@@ -25,10 +25,23 @@ struct SoilThermalEqn {
   double den, yexp, flux_term1;
   double inv_den;
   int steep;
-  VIC_DEV void prepare(double B, double bubble, double expt, int node) {
-    den = 9.81 * bubble / 100.;
-    inv_den = 1.0 / (273.16 * den);
-    yexp = -(2.0 / (expt - 3.0));
+  // the two per-node constants of the curve, computed once per step when the item block is written (profile_item_store)
+  static VIC_DEV double curve_exponent(double expt) { return -(2.0 / (expt - 3.0)); }
+  static VIC_DEV double curve_divisor(double bubble) {
+    const double d = 9.81 * bubble / 100.;
+#ifdef VIC_REFERENCE_DIVISIONS
+    return d;
+#else
+    return 1.0 / (273.16 * d);
+#endif
+  }
+  VIC_DEV void prepare(double B, double curve_div, double curve_exp, int node) {
+#ifdef VIC_REFERENCE_DIVISIONS
+    den = curve_div;
+#else
+    inv_den = curve_div;
+#endif
+    yexp = curve_exp;
     flux_term1 = B * (TL - TU);
     steep = (node == 1 && fabs(TL - TU) > 5.) ? 1 : 0;
   }
@@ -83,7 +96,7 @@ struct SoilThermalEqn {
 #define PROFILE_RECORD_DOUBLES 12
 #endif
 constexpr int PREC = PROFILE_RECORD_DOUBLES;     // 12 used
-enum { PR_T0 = 0, PR_A, PR_B, PR_C, PR_D, PR_EI, PR_E, PR_MOIST, PR_ICE, PR_MAXM, PR_BUB, PR_EXPT };
+enum { PR_T0 = 0, PR_A, PR_B, PR_C, PR_D, PR_EI, PR_E, PR_MOIST, PR_ICE, PR_MAXM, PR_CURVE_DIV, PR_CURVE_EXP };
 
 template <int NN>
 VIC_DEV void profile_item_store(const Opt& o, const CellView& cv, const Soil3& s3, const Nodes<NN>& nd, double deltat, bool frozen_on,
@@ -117,10 +130,12 @@ VIC_DEV void profile_item_store(const Opt& o, const CellView& cv, const Soil3& s
     }
     r[PR_EI] = E * (0. - nd.ice[j]);
     r[PR_E] = E; r[PR_MOIST] = nd.moist[j]; r[PR_ICE] = nd.ice[j];
+    double bub, ex;
     if (o.frozen_compat) {
-      if (j < 3) { r[PR_MAXM] = s3.max_moist[j]; r[PR_BUB] = cv.lay(CPL_BUBBLE, j); r[PR_EXPT] = cv.lay(CPL_EXPT, j); }
-      else { r[PR_MAXM] = cv.node(CPN_MAX_MOIST, j - 3); r[PR_BUB] = cv.node(CPN_BUBBLE, j - 3); r[PR_EXPT] = cv.node(CPN_EXPT, j - 3); }
-    } else { r[PR_MAXM] = cv.node(CPN_MAX_MOIST, j); r[PR_BUB] = cv.node(CPN_BUBBLE, j); r[PR_EXPT] = cv.node(CPN_EXPT, j); }
+      if (j < 3) { r[PR_MAXM] = s3.max_moist[j]; bub = cv.lay(CPL_BUBBLE, j); ex = cv.lay(CPL_EXPT, j); }
+      else { r[PR_MAXM] = cv.node(CPN_MAX_MOIST, j - 3); bub = cv.node(CPN_BUBBLE, j - 3); ex = cv.node(CPN_EXPT, j - 3); }
+    } else { r[PR_MAXM] = cv.node(CPN_MAX_MOIST, j); bub = cv.node(CPN_BUBBLE, j); ex = cv.node(CPN_EXPT, j); }
+    r[PR_CURVE_DIV] = SoilThermalEqn::curve_divisor(bub); r[PR_CURVE_EXP] = SoilThermalEqn::curve_exponent(ex);
   }
 }
 
