@@ -894,9 +894,10 @@ struct FdChunk {
   int* d_list[2] = {nullptr, nullptr};   // work lists (HRU ids)
   int* d_count = nullptr;          // [l * NBUCKET + b] segment sizes of list l, then CNT_CURSOR, CNT_EVALONLY
   int list_cap = 0;                // entries per segment
-  int* h_count = nullptr;          // pinned read-back
+  int* h_count = nullptr;          // pinned read-back, two slots of CNT_TOTAL
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
+  hipEvent_t readback[2] = {nullptr, nullptr};
   std::string err;
   int status = 0;
   long long rounds = 0, steps = 0;
@@ -942,6 +943,7 @@ static void free_domain(vicgpu_ctx* c) {
     HIPIGN(hipFree(ch.d_glist)); HIPIGN(hipFree(ch.d_list[0])); HIPIGN(hipFree(ch.d_list[1])); HIPIGN(hipFree(ch.d_count));
     if (ch.h_count) HIPIGN(hipHostFree(ch.h_count));
     if (ch.done) HIPIGN(hipEventDestroy(ch.done));
+    for (hipEvent_t e : ch.readback) if (e) HIPIGN(hipEventDestroy(e));
     if (ch.stream) HIPIGN(hipStreamDestroy(ch.stream));
   }
   c->chunks.clear();
@@ -1037,6 +1039,7 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
     int nmax = ch->gcount;
+    int pending = -1, pending_list = 0;        // read-back slot issued and not yet looked at, and the list it counts
     for (int round = 0;; round++) {
       pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur * NBUCKET; pa.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
       pa.evalonly_zero = ch->d_count + CNT_EVALONLY;
@@ -1047,12 +1050,24 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
       CHKCH(ch, hipGetLastError());
       cur ^= 1;
       ch->rounds++;
-      if (round + 1 >= FREE_ROUNDS) {
-        int n = 0, ne = 0;
-        const int r = fd_read_count(ch, cur, &n, &ne);
-        if (r != VICGPU_OK) return r;
+      // The list sizes are read back one round late: the copy issued after the previous round sits in the stream ahead of
+      // the kernels just launched, so waiting for it never leaves the GPU idle.  The price is one round on empty lists at
+      // the end (both kernels return at once; the lists and counters stay empty).
+      if (pending >= 0) {
+        CHKCH(ch, hipEventSynchronize(ch->readback[pending]));
+        const int* h = ch->h_count + pending * CNT_TOTAL;
+        int n = 0;
+        for (int b = 0; b < NBUCKET; b++) n += h[pending_list * NBUCKET + b];
+        const int ne = h[CNT_EVALONLY];
+        pending = -1;
         if (n == 0 && ne == 0) break;
         nmax = n;
+      }
+      if (round + 2 >= FREE_ROUNDS) {
+        const int slot = round & 1;
+        CHKCH(ch, hipMemcpyAsync(ch->h_count + slot * CNT_TOTAL, ch->d_count, sizeof(int) * CNT_TOTAL, hipMemcpyDeviceToHost, st));
+        CHKCH(ch, hipEventRecord(ch->readback[slot], st));
+        pending = slot; pending_list = cur;
       }
     }
     ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET;
@@ -1286,10 +1301,11 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
       HIPCHK(c, hipMalloc(&ch.d_list[0], gb * NBUCKET));
       HIPCHK(c, hipMalloc(&ch.d_list[1], gb * NBUCKET));
       HIPCHK(c, hipMalloc(&ch.d_count, sizeof(int) * CNT_TOTAL));
-      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * CNT_TOTAL, hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * CNT_TOTAL * 2, hipHostMallocDefault));
       if (ch.gcount) HIPCHK(c, hipMemcpy(ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
       HIPCHK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
       HIPCHK(c, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
+      for (hipEvent_t& e : ch.readback) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
   }
   return VICGPU_OK;
