@@ -1,0 +1,74 @@
+"""Option-branch scenarios shared by the oracle-vs-reference tests (tests/test_oracle.py) and the GPU parity tests
+(tests/test_gpu_parity.py): one entry per run-time option branch of the path (vic_amd/csrc/vic_types.hpp Opt,
+SURVEY.md Appendix B), so that no branch is implemented without being pinned oracle-vs-reference AND device-vs-oracle.
+
+Each entry: name -> dict(kw=option overrides, variant=reference build (plain/fixed/compat), ncell, ntile, glacier,
+nsteps (side-by-side run length), doy (start day of year), tweak=optional name of a domain/forcing modifier below).
+"""
+import numpy as np
+
+from vic_amd import abi, domain
+from vic_amd.abi import C
+
+FROZEN = dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=0)
+
+OPTION_BRANCHES = {
+    # finite-difference soil heat variants (frozen_soil.c:181-212)
+    "frozen_exp_trans": dict(kw=dict(FROZEN, EXP_TRANS=1), variant="fixed", ncell=4, ntile=2, nsteps=150, doy=330),
+    "frozen_exp_trans_noflux": dict(kw=dict(FROZEN, EXP_TRANS=1, NOFLUX=1), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=10),
+    "frozen_noflux": dict(kw=dict(FROZEN, NOFLUX=1), variant="fixed", ncell=4, ntile=2, nsteps=120, doy=1),
+    "frozen_n12": dict(kw=dict(FROZEN, Nnode=12), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=300),
+    "frozen_n18": dict(kw=dict(FROZEN, Nnode=18), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=20),
+    "frozen_n5": dict(kw=dict(FROZEN, Nnode=5), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=320),
+    # ground heat flux forms (func_surf_energy_bal.c:176-182, 234-276)
+    "gf_406": dict(kw=dict(FULL_ENERGY=1, GRND_FLUX_TYPE=C["VIC_GF_406"]), variant="plain", ncell=6, ntile=3, nsteps=200, doy=80),
+    "gf_full": dict(kw=dict(FULL_ENERGY=1, GRND_FLUX_TYPE=C["VIC_GF_FULL"]), variant="plain", ncell=6, ntile=3, nsteps=200, doy=80),
+    "gf_406_frozen": dict(kw=dict(FROZEN, GRND_FLUX_TYPE=C["VIC_GF_406"]), variant="fixed", ncell=4, ntile=3, nsteps=120, doy=330),
+    "gf_full_frozen": dict(kw=dict(FROZEN, GRND_FLUX_TYPE=C["VIC_GF_FULL"]), variant="fixed", ncell=4, ntile=3, nsteps=120, doy=330),
+    # canopy-snow aerodynamic resistance variants (func_canopy_energy_bal.c:50-95): winter, overstory tiles
+    "ar_406": dict(kw=dict(FULL_ENERGY=1, AERO_RESIST_CANSNOW=C["VIC_AR_406"]), variant="plain", ncell=6, ntile=3, nsteps=240, doy=350),
+    "ar_406_ls": dict(kw=dict(FULL_ENERGY=1, AERO_RESIST_CANSNOW=C["VIC_AR_406_LS"]), variant="plain", ncell=6, ntile=3, nsteps=240, doy=350),
+    "ar_410": dict(kw=dict(FULL_ENERGY=1, AERO_RESIST_CANSNOW=C["VIC_AR_410"]), variant="plain", ncell=6, ntile=3, nsteps=240, doy=350),
+    "ar_combo": dict(kw=dict(FULL_ENERGY=1, AERO_RESIST_CANSNOW=C["VIC_AR_COMBO"]), variant="plain", ncell=6, ntile=3, nsteps=240, doy=350),
+    # snow parameterisations (snow_utility.c:9-307, calc_rainonly.c:56-95)
+    "snthrm": dict(kw=dict(FULL_ENERGY=1, SNOW_DENSITY=C["VIC_DENS_SNTHRM"]), variant="plain", ncell=6, ntile=3, nsteps=240, doy=1),
+    "sun1999": dict(kw=dict(FULL_ENERGY=1, SNOW_ALBEDO=C["VIC_SNOW_ALBEDO_SUN1999"]), variant="plain", ncell=6, ntile=3, nsteps=240, doy=60),
+    "vic412": dict(kw=dict(FULL_ENERGY=1, TEMP_TH_TYPE=C["VIC_TEMP_TH_VIC_412"]), variant="plain", ncell=6, ntile=3, nsteps=240, doy=80),
+    "snthrm_frozen": dict(kw=dict(FROZEN, SNOW_DENSITY=C["VIC_DENS_SNTHRM"], SNOW_ALBEDO=C["VIC_SNOW_ALBEDO_SUN1999"]), variant="fixed",
+                          ncell=4, ntile=3, nsteps=100, doy=20),
+    # solver error handling: TFALLBACK off, undisturbed and with forcing that makes the root finders fail
+    "tfallback0": dict(kw=dict(FULL_ENERGY=1, TFALLBACK=0), variant="plain", ncell=6, ntile=3, nsteps=200, doy=70),
+    "tfallback0_frozen": dict(kw=dict(FROZEN, TFALLBACK=0), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=330),
+    "stress_fallback": dict(kw=dict(FULL_ENERGY=1, TFALLBACK=1), variant="plain", ncell=8, ntile=3, nsteps=96, doy=70, tweak="stress"),
+    "stress_fallback_frozen": dict(kw=dict(FROZEN, TFALLBACK=1), variant="fixed", ncell=6, ntile=2, nsteps=72, doy=330, tweak="stress"),
+    "stress_error": dict(kw=dict(FULL_ENERGY=1, TFALLBACK=0), variant="plain", ncell=8, ntile=3, nsteps=96, doy=70, tweak="stress",
+                         expect_errors=True),
+    # GLACIER_DYNAMICS: zero-area glacier HRUs still run (full_energy.c:220, 389)
+    "glacier_dynamics": dict(kw=dict(FULL_ENERGY=1, Nband=3, GLACIER_DYNAMICS=1), variant="plain", ncell=6, ntile=2, glacier=True,
+                             nsteps=200, doy=120, tweak="zero_area_glacier"),
+    "glacier_dynamics_frozen": dict(kw=dict(FROZEN, Nband=2, GLACIER_DYNAMICS=1), variant="fixed", ncell=4, ntile=2, glacier=True,
+                                    nsteps=100, doy=100, tweak="zero_area_glacier"),
+}
+
+
+def build(name, nsteps=None):
+    """Domain + forcing of a scenario: returns (spec, d, f, sf, dmy)."""
+    sp = OPTION_BRANCHES[name]
+    opt = abi.default_options(**sp["kw"])
+    d = domain.make_domain(sp["ncell"], opt, ntile=sp["ntile"], glacier_top_band=sp.get("glacier", False))
+    n = nsteps or sp["nsteps"]
+    f, sf, dmy = domain.make_forcing(d, 0, n, start_doy=sp["doy"])
+    tw = sp.get("tweak")
+    if tw == "stress":
+        # every 7th step one third of the cells receive a shortwave flux no surface temperature within the solvers'
+        # search range (+-51 K, root_brent.c:183-248) can balance: the root finders fail -> fallback (or ERROR)
+        sw = C["VIC_F_SHORTWAVE"]
+        cells = np.arange(d.ncell) % 3 == 1
+        for s in range(5, n, 7):
+            f[s, sw][:, cells] = 60000.0
+    elif tw == "zero_area_glacier":
+        # glacier HRUs of every second cell lose their area (Cv = 0): skipped without GLACIER_DYNAMICS, run with it
+        isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+        cell = d.hru_iparams[C["HPI_CELL"]]
+        d.hru_dparams[C["HPD_CV"], isg & (cell % 2 == 0)] = 0.0
+    return sp, d, f, sf, dmy

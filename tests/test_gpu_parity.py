@@ -12,7 +12,9 @@ import pytest
 
 from vic_amd import abi, domain, init_state
 from vic_amd.abi import C
-from tests.util import rel_diff, worst, FLUX_ROWS_COMMON
+from tests import scenarios
+from tests.golden_util import golden_names, load_golden
+from tests.util import rel_diff, worst, FLUX_ROWS_COMMON, active_hrus
 
 pytestmark = pytest.mark.gpu
 
@@ -91,10 +93,121 @@ def test_teacher_forced(name, oracle_lib):
         assert w1 < TF_TOL, "step %d state %s" % (s, m1)
         assert w2 < TF_TOL, "step %d flux %s" % (s, m2)
         assert w3 < TF_TOL, "step %d cell %s" % (s, m3)
-        # integer state (flags, counters, last_snow) must agree exactly unless a solver fell back on one side only
-        assert (io == ig).mean() > 0.999, "step %d int state mismatch at %s" % (s, np.argwhere(io != ig)[:4])
+        assert_int_state_equal(io, ig, d.opt.Nnode, "step %d" % s)
         worst_all = max(worst_all, w1, w2, w3)
     print(name, "teacher-forced worst rel diff %.3e" % worst_all)
+
+
+def assert_int_state_equal(io, ig, Nn, where):
+    """Integer state: snow flags, last_snow, MELTING, frozen / front counts, every fallback flag and counter -- all rows
+    exactly equal, no exception list.  (A solver that falls back on one side only would show up here as a fallback row
+    mismatch AND as a temperature mismatch far above the 1e-6 of the double rows.)"""
+    if not np.array_equal(io, ig):
+        names = {v: k for k, v in C.items() if k.startswith("SI_")}
+        bad = np.argwhere(io != ig)
+        r, c = bad[0]
+        raise AssertionError("%s: %d integer state entries differ, first %s%s hru %d: oracle %d gpu %d" % (
+            where, len(bad), names.get(int(r), "node row "), "" if int(r) in names else int(r) - C["SI_NSCALAR"], c, io[r, c], ig[r, c]))
+
+
+@pytest.mark.parametrize("name", list(scenarios.OPTION_BRANCHES))
+def test_teacher_forced_option_branches(name, oracle_lib):
+    """One case per run-time option branch of the device code (tests/scenarios.py; each is pinned oracle-vs-reference in
+    tests/test_oracle.py): EXP_TRANS, NOFLUX, node counts 5/12/18 on the generic template, GRND_FLUX_TYPE, every
+    AERO_RESIST_CANSNOW variant, SNTHERM, SUN1999, VIC_412, TFALLBACK off, forced solver failures (fallback flags and
+    counters with TFALLBACK on, per-cell error bits with it off), GLACIER_DYNAMICS with zero-area glacier HRUs."""
+    from vic_amd.api import Model
+    sp, d, f, sf, dmy = scenarios.build(name, nsteps=36)
+    nsteps = f.shape[0]
+    sd0, si0 = init_state.initial_state(d, f[0])
+    isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+    if sp.get("glacier"):
+        sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    gpu = Model(d)
+    gpu.push_forcing(f, sf, dmy)
+    cell = d.hru_iparams[C["HPI_CELL"]]
+    worst_all, nerr, nfb = 0.0, 0, 0
+    for s in range(nsteps):
+        sd_in, si_in = orc.get_state()
+        fo, co, eo = orc.step(f[s], sf[s], dmy[s])
+        so, io = orc.get_state()
+        gpu.set_state(sd_in, si_in)
+        gpu.reset_accum()                        # also clears the (sticky) per-cell error bits
+        gpu.dist_prec(s, 1)
+        sg, ig = gpu.get_state()
+        fg = gpu.get_fluxes()
+        cg = gpu.get_cell_outputs()
+        eg = gpu.get_cell_errors()
+        # the cells whose step returned ERROR (vicNl.c:545-559) are the same on both sides
+        assert np.array_equal(eo != 0, eg != 0), "step %d error cells: oracle %s gpu %s" % (s, np.flatnonzero(eo), np.flatnonzero(eg))
+        if not sp.get("expect_errors"):
+            assert eo.sum() == 0
+        nerr += int((eo != 0).sum())
+        # the reference leaves an erroring cell half-updated (its HRU loop stops at the failing HRU); the device finishes
+        # the other HRUs of that cell.  Compare the cells that completed.
+        okh = (eo == 0)[cell]
+        so, sg, io, ig = so[:, okh], sg[:, okh], io[:, okh], ig[:, okh]
+        assert np.nanmax(np.abs(so[C["SD_ERROR"]] - sg[C["SD_ERROR"]])) < 1e-3
+        so[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
+        w1, m1 = worst(so, sg, "SD_", floor=1e-6)
+        rows = FLUX_ROWS_COMMON + (GLACIER_ROWS if sp.get("glacier") else [])
+        act = active_hrus(d, glacier_dynamics=bool(d.opt.GLACIER_DYNAMICS)) & okh
+        w2, m2 = worst(fo[rows][:, act], fg[rows][:, act], "FX_", floor=1e-6)
+        w3, m3 = worst(co[:, eo == 0], cg[:, eo == 0], "CO_", floor=1e-6)
+        assert w1 < TF_TOL, "step %d state %s" % (s, m1)
+        assert w2 < TF_TOL, "step %d flux %s" % (s, m2)
+        assert w3 < TF_TOL, "step %d cell %s" % (s, m3)
+        assert_int_state_equal(io, ig, d.opt.Nnode, "step %d" % s)
+        nfb += int(io[C["SI_TSURF_FBFLAG"]].sum())
+        worst_all = max(worst_all, w1, w2, w3)
+    if sp.get("expect_errors"):
+        assert nerr > 0
+    if sp.get("tweak") == "stress" and not sp.get("expect_errors"):
+        assert nfb > 0
+    print(name, "teacher-forced worst rel diff %.3e, %d cell errors, %d fallbacks" % (worst_all, nerr, nfb))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_gpu_against_reference_goldens(name):
+    """The committed trajectory goldens (tests/golden/*.npz: states, fluxes and cell outputs of the REAL reference,
+    generated by tests/golden/make_golden.py) straight onto the device, no oracle in between: from every stored reference
+    state the HIP path runs the `stride` steps to the next stored one and must land on the reference's state, fluxes and
+    cell outputs (1e-5 relative: a few free-running steps; measured values are printed)."""
+    from vic_amd.api import Model
+    d, z = load_golden(name)
+    f, sf, dmy = z["forcing"], z["snowflag"], z["dmy"]
+    steps = [int(s) for s in z["steps"]]
+    gpu = Model(d)
+    gpu.push_forcing(f, sf, dmy)
+    rows = FLUX_ROWS_COMMON + (GLACIER_ROWS if (d.hru_iparams[C["HPI_IS_GLACIER"]] != 0).any() else [])
+    isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+    sd, si, s_from = z["sd0"], z["si0"].astype(np.int32), 0
+    worst_all = 0.0
+    for k, s_to in enumerate(steps):
+        gpu.set_state(sd, si)
+        gpu.dist_prec(s_from, s_to + 1 - s_from)
+        sg, ig = gpu.get_state()
+        fg, cg = gpu.get_fluxes(), gpu.get_cell_outputs()
+        assert gpu.get_cell_errors().sum() == 0
+        sr, ir, fr, cr = z["states_d"][k].copy(), z["states_i"][k], z["fluxes"][k], z["cells"][k]
+        assert np.nanmax(np.abs(sr[C["SD_ERROR"]] - sg[C["SD_ERROR"]])) < 1e-2
+        sr[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
+        w1, m1 = worst(sr, sg, "SD_", floor=1e-4)
+        # glacier rows of non-glacier HRUs are undefined on both sides
+        w2, m2 = worst(fr[FLUX_ROWS_COMMON][:, ~isg], fg[FLUX_ROWS_COMMON][:, ~isg], "FX_", floor=1e-4)
+        w3, m3 = worst(cr, cg, "CO_", floor=1e-4)
+        assert w1 < FREE_TOL, "reference step %d state %s" % (s_to, m1)
+        assert w2 < FREE_TOL, "reference step %d flux %s" % (s_to, m2)
+        assert w3 < FREE_TOL, "reference step %d cell %s" % (s_to, m3)
+        if isg.any():
+            w4, m4 = worst(fr[GLACIER_ROWS][:, isg], fg[GLACIER_ROWS][:, isg], "FX_", floor=1e-4)
+            assert w4 < FREE_TOL, "reference step %d glacier flux %s" % (s_to, m4)
+        assert_int_state_equal(ir, ig, d.opt.Nnode, "reference step %d" % s_to)
+        worst_all = max(worst_all, w1, w2, w3)
+        sd, si, s_from = z["states_d"][k], z["states_i"][k].astype(np.int32), s_to + 1
+    print(name, "HIP path vs reference golden, worst rel diff %.3e over %d segments" % (worst_all, len(steps)))
 
 
 @pytest.mark.parametrize("name", ["quickflux_melt", "bands", "waterbalance_daily", "frozen_fixed", "glacier_summer"])

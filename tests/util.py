@@ -57,11 +57,16 @@ def edge_domain(opt, ncell=24, ntile=3, seed=7):
     return d
 
 
-def active_hrus(d):
-    """HRUs the step actually computes (full_energy.c:220-231: Cv > 0 and the band has area); the flux rows of the others
-    are not defined by either implementation (put_data never reads them)."""
+def active_hrus(d, glacier_dynamics=False):
+    """HRUs the step actually computes (full_energy.c:220-231: Cv > 0 and the band has area; with GLACIER_DYNAMICS also
+    glacier HRUs without area); the flux rows of the others are not defined by either implementation (put_data never
+    reads them)."""
     from vic_amd import abi
     hpd, hpi, cp, opt = d.hru_dparams, d.hru_iparams, d.cell_params, d.opt
     cell, band = hpi[C["HPI_CELL"]], hpi[C["HPI_BAND"]]
     area = np.array([cp[abi.cp_band(C["CPB_AREAFRACT"], b, opt.Nnode, opt.Nband), c] for b, c in zip(band, cell)])
-    return (hpd[C["HPD_CV"]] > 0) & (area > 0)
+    act = (hpd[C["HPD_CV"]] > 0) & (area > 0)
+    if glacier_dynamics:
+        isg = hpi[C["HPI_IS_GLACIER"]] != 0
+        act = act | (isg & (hpd[C["HPD_CV"]] >= 0) & (area >= 0))
+    return act
