@@ -1,46 +1,57 @@
 #!/usr/bin/env python3
 """Benchmark of the VIC hot path (dist_prec -> full_energy -> surface_fluxes) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg4|cfg2]
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg4|cfg2] [--compat]
 
 A "step" is one model time step of every cell of the rank's shard (all HRUs, all snow sub-steps).
-Metric: cell-timesteps/s, whole job (sum over ranks).  Weak scaling: every rank owns a full copy of the
-per-GPU workload (cells shard trivially, no data-path collective; BASELINE.json cfg4 = 8 x 125k cells).
+Metric: cell-timesteps/s, whole job (sum over ranks).
+
+Launching.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (one process per GPU,
+`python -m torch.distributed.run --nproc-per-node N ...`, RCCL) BEFORE anything in this process touches the GPU, waits
+for them and exits with their code; started under torch.distributed.run already (WORLD_SIZE set), it is one of the ranks.
 
 Workloads (BASELINE.json configs, SURVEY.md 8(d) synthetic inputs):
-  cfg3  100k cells, FULL_ENERGY + FROZEN_SOIL (10 thermal nodes, explicit, "fixed" node-parameter semantics),
-        5 snow bands x 5 veg tiles = 25 HRUs/cell, hourly  -- the config the metric is quoted on (default)
-  cfg4  one GPU's share (125k cells) of the 1M-cell glacier config: cfg3 with veg slot 0 of the top band a glacier HRU
+  cfg3  100k cells, FULL_ENERGY + FROZEN_SOIL (10 thermal nodes, explicit), 5 snow bands x 5 veg tiles = 25 HRUs/cell,
+        hourly -- the config the metric is quoted on (default at N = 1)
+  cfg4  BASELINE configs[3]: the glacier domain (cfg3 + veg slot 0 of the top band a glacier HRU) sharded over the ranks,
+        125k cells per GPU = 1M cells at N = 8 (default at N > 1; weak scaling: the per-GPU share is fixed).  Every rank
+        builds ITS block of the one N x 125k-cell domain (domain.make_domain(cell_range=...) == shard.shard_domain of it).
   cfg2  10k cells, FULL_ENERGY (QUICK_FLUX), 1 band x 3 veg tiles, hourly
+FROZEN_SOIL semantics: "fixed" (node arrays, oracle patch P2) by default, `--compat` = the reference as shipped
+(frozen_soil.c:218-221 layer arrays indexed by node; SURVEY.md Finding 1.2).
 
 Forcing for all W+K steps is generated on the host and is resident in HBM before the timed region starts.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CELLS_PER_GPU_CFG4 = 125000
 
 
-def config(name):
+def config(name, compat=False):
     from vic_amd import abi
+    fc = 1 if compat else 0
+    sem = "compat" if compat else "fixed"
     if name == "cfg3":
-        opt = abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5, frozen_compat=0)
+        opt = abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5, frozen_compat=fc)
         return dict(opt=opt, ncell=100000, ntile=5, start_doy=60,
-                    workload="cfg3: 100k cells, FULL_ENERGY+FROZEN_SOIL (Nnode=10, explicit, fixed), 5 bands x 5 veg tiles, hourly")
-    if name == "cfg4":       # one GPU's share of BASELINE.json configs[3] (1M cells on 8 GPUs): cfg3 + a glacier HRU in the top band
-        opt = abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5, frozen_compat=0)
-        return dict(opt=opt, ncell=125000, ntile=5, start_doy=60, glacier=True,
-                    workload="cfg4 share: 125k cells (1M / 8 GPUs), FULL_ENERGY+FROZEN_SOIL (Nnode=10, explicit, fixed), 5 bands x 5 veg tiles, "
-                             "veg slot 0 of the top band = glacier (solve_glacier / surface_fluxes_glac), hourly")
+                    workload="cfg3: 100k cells, FULL_ENERGY+FROZEN_SOIL (Nnode=10, explicit, %s), 5 bands x 5 veg tiles, hourly" % sem)
+    if name == "cfg4":       # BASELINE.json configs[3] (1M cells on 8 GPUs): cfg3 + a glacier HRU in the top band
+        opt = abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5, frozen_compat=fc)
+        return dict(opt=opt, ncell=CELLS_PER_GPU_CFG4, ntile=5, start_doy=60, glacier=True,
+                    workload="cfg4: 125k cells per GPU (1M cells on 8 GPUs), FULL_ENERGY+FROZEN_SOIL (Nnode=10, explicit, %s), "
+                             "5 bands x 5 veg tiles, veg slot 0 of the top band = glacier (solve_glacier / surface_fluxes_glac), hourly" % sem)
     if name == "cfg2":
         opt = abi.default_options(FULL_ENERGY=1)
         return dict(opt=opt, ncell=10000, ntile=3, start_doy=60,
@@ -89,17 +100,61 @@ def cpu_baseline(cfg, target_seconds=15.0):
                 ncell_s, nsteps, secs, "reference build oracle/_ref/libvicref_%s.so" % variant if kind == "reference" else "oracle/libvicoracle.so")}
 
 
-def measured_traffic(config_name, ncell):
-    """HBM bytes per step from the committed PMC passes of this workload (profiles/r01_traffic.json, written by
-    tools/round_summary.py from separate FETCH_SIZE / WRITE_SIZE passes); None when no measurement matches."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+def csrc_digest():
+    """Content hash of the device sources + ABI header: the build a committed profile belongs to (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vic_amd", "csrc")
+    for fn in sorted(os.listdir(d)) + [os.path.join(ROOT, "include", "vicgpu.h")]:
+        with open(fn if os.path.isabs(fn) else os.path.join(d, fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(config_name, ncell, compat):
+    """HBM bytes per step from the committed PMC passes of this workload (profiles/traffic_<config>.json, written by
+    tools/round_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command).  The file is stamped with the
+    digest of the device sources it was measured on; a stale stamp (any kernel source changed since) gives None."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s%s.json" % (config_name, "_compat" if compat else ""))
     if not os.path.exists(path):
-        return None
+        return None, "no PMC measurement committed for this workload"
     with open(path) as f:
         t = json.load(f)
     if t.get("config") != config_name or t.get("cells_per_gpu") != ncell:
-        return None
-    return t.get("hbm_bytes_per_step")
+        return None, "committed PMC measurement is for another size"
+    if t.get("csrc_digest") != csrc_digest():
+        return None, "committed PMC measurement is stale (device sources changed since %s)" % t.get("round", "?")
+    return t.get("hbm_bytes_per_step"), "profiles/%s: %s" % (os.path.basename(path), t.get("method", ""))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(ngpus, argv):
+    """One process per GPU through torch.distributed.run; this (parent) process never initialises the GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args):
+    """`--launch-check`: the ranks only rendezvous (gloo, no GPU) and report who is there -- the CPU test of the launcher."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    pids = [None] * world
+    dist.all_gather_object(pids, os.getpid())
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "gpus_requested": args.gpus, "ranks_seen": world, "pids": pids}))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -107,18 +162,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--config", default=None, help="cfg3 (default at 1 GPU), cfg4 (default at > 1 GPU), cfg2")
+    ap.add_argument("--compat", action="store_true", help="FROZEN_SOIL as the reference ships it (frozen_soil.c:218-221) instead of 'fixed'")
     ap.add_argument("--ncell", type=int, default=0, help="override cells per GPU (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))        # nothing above has touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d: launch with `python bench.py --gpus N` or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -127,22 +191,32 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ranks_seen = dist.get_world_size() if use_dist else 1
+    assert ranks_seen == world
 
-    from vic_amd import domain, init_state
+    from vic_amd import domain, init_state, shard
     from vic_amd.api import Model
     from vic_amd.abi import C
 
-    cfg = config(args.config)
+    cfg_name = args.config or ("cfg3" if world == 1 else "cfg4")
+    cfg = config(cfg_name, compat=args.compat)
     opt = cfg["opt"]
     ncell = args.ncell or cfg["ncell"]
     K, W = args.steps, args.warmup
-    # every rank builds its own shard: a different seed = different cells, same statistics (cells never interact)
-    d = domain.make_domain(ncell, opt, ntile=cfg["ntile"], glacier_top_band=cfg.get("glacier", False), seed=domain.SEED + rank)
+    # ONE domain of world x ncell cells, cut into contiguous HRU-balanced blocks (shard.partition_cells: every cell has the
+    # same number of HRUs here, so the blocks are equal); this rank builds only its block
+    ncell_global = ncell * world
+    c0, c1 = rank * ncell, (rank + 1) * ncell
+    d = domain.make_domain(ncell_global, opt, ntile=cfg["ntile"], glacier_top_band=cfg.get("glacier", False), cell_range=(c0, c1))
     f, sf, dmy = domain.make_forcing(d, 0, W + K, start_doy=cfg["start_doy"])
     sd0, si0 = init_state.initial_state(d, f[0])
+    if cfg.get("glacier"):
+        # the driver opens the glacier mass-balance accumulation window (accumulateGlacierMassBalance.c:13-67)
+        isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+        sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
     m = Model(d, device=local_rank)
     m.set_state(sd0, si0)
-    m.set_write_fluxes(False)          # production setting: per-cell accumulators only, no per-HRU flux table
+    m.set_write_fluxes(False)          # production setting: per-cell outputs only, no per-HRU flux table
     m.push_forcing(f, sf, dmy)
     m.synchronize()
     del f
@@ -173,36 +247,43 @@ def main():
     if use_dist:
         # the one exchange of the path: the per-cell output table to the writer, RCCL all-gather over xGMI;
         # outside the timed region (it happens once per output step, not per model step)
-        from vic_amd import shard
         barrier()
         tg = time.perf_counter()
         full = shard.gather_cell_table(acc, [ncell] * world, device=torch.device("cuda", local_rank))
         barrier()
         gather_ms = (time.perf_counter() - tg) * 1e3
-        assert full.shape == (acc.shape[0], ncell * world)
+        assert full.shape == (acc.shape[0], ncell_global)
+        assert np.array_equal(full[:, c0:c1], acc, equal_nan=True)          # this rank's block arrived where the writer expects it
+        nerr_t = torch.tensor([nerr], device="cuda", dtype=torch.int64)
+        dist.all_reduce(nerr_t)
+        nerr = int(nerr_t.item())
 
     if rank == 0:
         hru_per_cell = d.nhru // d.ncell
         balg = b_alg(opt, hru_per_cell)
         value = world * ncell * K / elapsed
         achieved = balg * ncell / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic, traffic_note = measured_traffic(cfg_name, ncell, args.compat)
+        mean_all = full if use_dist else acc
         out = {
             "metric": "cell-timesteps/s", "value": value, "unit": "cell-timesteps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["workload"], "cells_per_gpu": ncell, "hru_per_cell": hru_per_cell,
-                       "parallelism": "cells sharded across %d GPU(s), no data-path collective" % world,
+            "config": {"workload": cfg["workload"], "cells_per_gpu": ncell, "cells_total": ncell_global, "hru_per_cell": hru_per_cell,
+                       "frozen_soil_semantics": ("compat" if opt.frozen_compat else "fixed") if opt.FROZEN_SOIL else None,
+                       "parallelism": "cells sharded across %d GPU(s) (one process per GPU, contiguous blocks of one domain), no data-path collective" % world,
+                       "ranks_seen_by_rccl": ranks_seen if use_dist else None,
                        "cells_with_error_flags": nerr, "output_gather_ms": gather_ms,
-                       "mean_runoff_mm_per_step": float(acc[C["CA_RUNOFF"]].mean() / max(1, K)),
-                       "mean_swe_mm_end": float(acc[C["CA_SWE_END"]].mean())},
+                       "mean_runoff_mm_per_step": float(mean_all[C["CA_RUNOFF"]].mean() / max(1, K)),
+                       "mean_swe_mm_end": float(mean_all[C["CA_SWE_END"]].mean())},
             # one "launch" of the hot path = one model step of the rank's cells: the QUICK_FLUX path is a single kernel, the
             # finite-difference path a pipeline of kernels (stage / profile solve / surface evaluation); the duration is
             # measured with HIP events on the library's streams around the whole step
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.config, ncell),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "vic_hru_step" if opt.QUICK_FLUX else "vic_fd_stage + vic_profile_solve + vic_surf_eval (per-step pipeline)",
                          "kernel_ms_per_launch": kernel_ms, "launches_timed": nlaunch,
-                         "algorithmic_bytes_per_cell_step": balg,
+                         "algorithmic_bytes_per_cell_step": balg, "csrc_digest": csrc_digest(),
                          "note": "fp64 VALU / divergence-bound root finding (SURVEY.md 7.3 #4): the algorithmic HBM fraction is small by construction; "
                                  "profiles/ holds the per-kernel rocprofv3 stats and PMC passes"},
         }

@@ -23,8 +23,10 @@
  * Option coverage: Nlayer = 3, DIST_PRCP = FALSE
  * (Ndist = 1, mu = 1), no lakes, no EXCESS_ICE / SPATIAL_FROST / SPATIAL_SNOW /
  * QUICK_FS / LOW_RES_MOIST / CLOSE_ENERGY (all compiled out in the reference,
- * user_def.h:36-92).  BLOWING, CORRPREC, IMPLICIT, QUICK_SOLVE are rejected by
- * vicgpu_create with VICGPU_ERR_UNSUPPORTED (SURVEY.md 8(f) "next").
+ * user_def.h:36-92).  CORRPREC is implemented.  The options struct carries IMPLICIT,
+ * BLOWING and QUICK_SOLVE so that a binding passes the reference's settings through
+ * unchanged: what the device code does not implement (see vicgpu_create) is REJECTED
+ * with VICGPU_ERR_UNSUPPORTED, never silently replaced by another solver.
  */
 #ifndef VICGPU_H_
 #define VICGPU_H_
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define VICGPU_ABI_VERSION 1
+#define VICGPU_ABI_VERSION 2
 
 #define VIC_NLAYER        3    /* MAX_LAYERS, user_def.h:95 */
 #define VIC_MAX_NODES    18    /* device build limit for options.Nnode (reference MAX_NODES = 50, user_def.h:96) */
@@ -91,7 +93,10 @@ typedef struct vicgpu_options {
                                SURVEY.md Finding 1.2); 0 = node arrays ("fixed") */
   int nveg_types;           /* veg_lib[0].NVegLibTypes; the table holds nveg_types + 4 rows */
   int CORRPREC;             /* gauge-undercatch correction of precipitation (correct_precip.c, full_energy.c:188-194) */
-  int reserved_i[2];
+  int IMPLICIT;             /* options.IMPLICIT: Newton-Raphson soil heat solver (frozen_soil.c:229-301, newt_raph_func_fast.c) */
+  int BLOWING;              /* options.BLOWING: blowing-snow sublimation (CalcBlowingSnow.c); rejected when set */
+  int QUICK_SOLVE;          /* options.QUICK_SOLVE (calc_surf_energy_bal.c:289-314, 400-475); rejected when set */
+  int reserved_i[1];
   double wind_h;            /* global_param.wind_h (m) */
   double reserved_d[3];
 } vicgpu_options;

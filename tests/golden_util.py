@@ -19,6 +19,8 @@ def load_golden(name):
     opt = abi.default_options()
     for k, v in zip(z["opt_names"], z["opt_values"]):
         k = str(k)
+        if k == "abi_version":
+            continue                      # the fixture stores data, not the ABI revision it was written through
         setattr(opt, k, float(v) if k == "wind_h" else int(v))
     d = domain.Domain()
     d.opt = opt

@@ -76,3 +76,24 @@ def test_shard_domain_partitions_cells():
         seen.append(g)
     allg = np.sort(np.concatenate(seen))
     assert np.array_equal(allg, np.arange(d.nhru))
+
+
+def test_cell_range_equals_shard_of_the_full_domain():
+    """bench.py's multi-GPU layout: every rank builds only its block of the one big domain
+    (domain.make_domain(cell_range=...)); that must be exactly what shard.shard_domain cuts out of the full domain --
+    parameter tables, HRU lists, initial moisture and the forcing of the block's cells."""
+    from vic_amd import shard
+    kw = dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5)
+    d = domain.make_domain(97, abi.default_options(**kw), ntile=5, glacier_top_band=True)
+    world = 4
+    b = shard.partition_cells(d.cell_hru_offset, world)
+    fg = domain.make_forcing(d, 0, 3, start_doy=60)
+    for r in range(world):
+        s1 = shard.shard_domain(d, r, world)
+        s2 = domain.make_domain(97, abi.default_options(**kw), ntile=5, glacier_top_band=True, cell_range=(b[r], b[r + 1]))
+        for k in ("cell_params", "hru_iparams", "hru_dparams", "cell_hru_offset", "cell_hru_list", "init_moist"):
+            assert np.array_equal(getattr(s1, k), getattr(s2, k), equal_nan=True), (r, k)
+        f1 = domain.make_forcing(s1, 0, 3, start_doy=60)
+        f2 = domain.make_forcing(s2, 0, 3, start_doy=60)
+        assert all(np.array_equal(x, y) for x, y in zip(f1, f2))
+        assert np.array_equal(f1[0], fg[0][..., b[r]:b[r + 1]]) and np.array_equal(f1[1], fg[1][..., b[r]:b[r + 1]])

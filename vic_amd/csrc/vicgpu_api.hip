@@ -909,6 +909,7 @@ struct vicgpu_ctx {
   int device;
   std::string err;
   int ncell = 0, nhru = 0, nveg_rows = 0;
+  bool domain_ready = false;       // set at the end of a successful vicgpu_set_domain, cleared by free_domain
   double *d_veglib = nullptr, *d_cp = nullptr, *d_hpd = nullptr, *d_sd = nullptr, *d_flux = nullptr, *d_forcing = nullptr,
          *d_cell_out = nullptr, *d_accum = nullptr;
   int *d_hpi = nullptr, *d_si = nullptr, *d_cell_off = nullptr, *d_cell_list = nullptr, *d_hru_err = nullptr, *d_cell_err = nullptr;
@@ -947,6 +948,9 @@ static void free_domain(vicgpu_ctx* c) {
     if (ch.stream) HIPIGN(hipStreamDestroy(ch.stream));
   }
   c->chunks.clear();
+  c->domain_ready = false;
+  c->chunk_steps = 0;              // a forcing chunk belongs to the domain it was pushed for (its rows are ncell wide)
+  c->dmy.clear();
   c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = c->d_pslot = c->d_hkey = nullptr;
   c->d_cp = c->d_hpd = c->d_sd = c->d_flux = c->d_cell_out = c->d_accum = nullptr;
   c->d_hpi = c->d_si = c->d_cell_off = c->d_cell_list = c->d_hru_err = c->d_cell_err = nullptr;
@@ -1154,6 +1158,8 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   if (opt->dt <= 0 || opt->snow_step <= 0 || opt->dt % opt->snow_step != 0) return VICGPU_ERR_ARG;
   if (opt->QUICK_FLUX && opt->Nnode != 3) return VICGPU_ERR_ARG;             // get_global_param.c:1151-1155
   if (opt->FROZEN_SOIL && opt->QUICK_FLUX) return VICGPU_ERR_ARG;            // get_global_param.c:376-381
+  // options of the reference this library does not implement are refused, never silently replaced
+  if (opt->BLOWING || opt->QUICK_SOLVE || opt->IMPLICIT) return VICGPU_ERR_UNSUPPORTED;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VICGPU_ERR_HIP;   // no CPU fallback: fail loudly
   if (device < 0 || device >= ndev) return VICGPU_ERR_ARG;
@@ -1208,8 +1214,23 @@ int vicgpu_set_veglib(vicgpu_ctx* c, int nrow, const double* veglib) {
   return VICGPU_OK;
 }
 
+static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cell_params, const int* hpi, const double* hpd,
+                           const int* cell_hru_offset, const int* cell_hru_list);
+
 int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_params, const int* hpi, const double* hpd,
                       const int* cell_hru_offset, const int* cell_hru_list) {
+  if (!c) return VICGPU_ERR_ARG;
+  const int r = set_domain_impl(c, ncell, nhru, cell_params, hpi, hpd, cell_hru_offset, cell_hru_list);
+  if (r == VICGPU_OK) c->domain_ready = true;
+  else if (r == VICGPU_ERR_HIP || r == VICGPU_ERR_NOMEM) {     // failed half-way: leave no partially built domain behind
+    HIPIGN(hipSetDevice(c->device));
+    free_domain(c);
+  }
+  return r;
+}
+
+static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cell_params, const int* hpi, const double* hpd,
+                           const int* cell_hru_offset, const int* cell_hru_list) {
   if (!c || ncell <= 0 || nhru <= 0 || !cell_params || !hpi || !hpd || !cell_hru_offset || !cell_hru_list) return VICGPU_ERR_ARG;
   // host-side shape checks: every index the kernels dereference is validated here, once
   if (cell_hru_offset[0] != 0 || cell_hru_offset[ncell] != nhru) return VICGPU_ERR_ARG;
@@ -1312,7 +1333,8 @@ int vicgpu_set_domain(vicgpu_ctx* c, int ncell, int nhru, const double* cell_par
 }
 
 int vicgpu_set_state(vicgpu_ctx* c, const double* sd, const int* si) {
-  if (!c || !c->d_sd || !sd || !si) return VICGPU_ERR_ARG;
+  if (!c || !sd || !si) return VICGPU_ERR_ARG;
+  if (!c->domain_ready) return VICGPU_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->d_sd, sd, sizeof(double) * VICGPU_SD_NROW(c->opt.Nnode) * c->nhru, hipMemcpyHostToDevice));
@@ -1321,7 +1343,8 @@ int vicgpu_set_state(vicgpu_ctx* c, const double* sd, const int* si) {
 }
 
 int vicgpu_get_state(vicgpu_ctx* c, double* sd, int* si) {
-  if (!c || !c->d_sd || !sd || !si) return VICGPU_ERR_ARG;
+  if (!c || !sd || !si) return VICGPU_ERR_ARG;
+  if (!c->domain_ready) return VICGPU_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(sd, c->d_sd, sizeof(double) * VICGPU_SD_NROW(c->opt.Nnode) * c->nhru, hipMemcpyDeviceToHost));
@@ -1330,7 +1353,8 @@ int vicgpu_get_state(vicgpu_ctx* c, double* sd, int* si) {
 }
 
 int vicgpu_push_forcing(vicgpu_ctx* c, int nsteps, const double* forcing, const unsigned char* snowflag, const int* dmy) {
-  if (!c || !c->d_cp || nsteps <= 0 || !forcing || !snowflag || !dmy) return VICGPU_ERR_ARG;
+  if (!c || nsteps <= 0 || !forcing || !snowflag || !dmy) return VICGPU_ERR_ARG;
+  if (!c->domain_ready) return VICGPU_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nsub = c->o.NR + 1;
   const size_t fbytes = sizeof(double) * (size_t)nsteps * VIC_NFORCE * nsub * c->ncell;
@@ -1360,7 +1384,8 @@ int vicgpu_push_forcing(vicgpu_ctx* c, int nsteps, const double* forcing, const 
 }
 
 int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
-  if (!c || !c->d_cp || !c->d_veglib || !c->d_forcing) return VICGPU_ERR_STATE;
+  if (!c) return VICGPU_ERR_ARG;
+  if (!c->domain_ready || !c->d_veglib || !c->d_forcing || c->chunk_steps <= 0) return VICGPU_ERR_STATE;
   if (step0 < 0 || nsteps <= 0 || step0 + nsteps > c->chunk_steps) return VICGPU_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->forcing_ready, 0));

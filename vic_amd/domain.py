@@ -223,7 +223,8 @@ class Domain:
     pass
 
 
-def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, seed=SEED, band_spread=400.0, bare_fraction=0.0):
+def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, seed=SEED, band_spread=400.0, bare_fraction=0.0,
+                cell_range=None):
     """Regular grid of `ncell` cells, opt.Nband snow bands x ntile veg tiles per band.
 
     HRU numbering is slot-major: hru = slot * ncell + cell with slot = tile * Nband + band, so a
@@ -233,31 +234,53 @@ def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, 
     bare_fraction > 0 leaves that fraction of every cell without vegetation, which read_vegparam.c:312-340 fills with one
     "artificial" bare-soil HRU per band (vegIndex = num_veg_types, Cv = (1 - Cv_sum) / Nband, no root zones); those HRUs
     take the last slots.
+
+    cell_range = (c0, c1) builds only cells [c0, c1) of the `ncell`-cell domain (one rank's shard of a multi-GPU run:
+    the per-cell random draws are made for the whole domain, everything derived from them only for the shard), with
+    exactly the tables shard.shard_domain would cut out of the full domain.
     """
     rng = np.random.default_rng(seed)
     Nn, Nb = opt.Nnode, opt.Nband
     d = Domain()
     d.opt = opt
-    d.ncell = ncell
+    ncell_global = ncell
+    c0, c1 = (0, ncell) if cell_range is None else (int(cell_range[0]), int(cell_range[1]))
+    assert 0 <= c0 < c1 <= ncell_global
+    sl = slice(c0, c1)
+    d.global_cell0 = c0
+    d.ncell_global = ncell_global
     veglib, nveg = make_veglib(glacier=glacier_top_band)
     opt.nveg_types = nveg
     if glacier_top_band:
         opt.GLACIER_ID = 22
     d.veglib = veglib
 
+    # the per-cell draws, in a fixed order, for the whole domain; the shard's slice of each
+    ng = ncell_global
+    u_d1 = rng.uniform(0.2, 0.5, ng)[sl]; u_d2 = rng.uniform(0.8, 2.0, ng)[sl]
+    b_infilt = rng.uniform(0.05, 0.4, ng)[sl]
+    Ds = rng.uniform(0.001, 0.3, ng)[sl]
+    Dsmax = rng.uniform(2, 30, ng)[sl]
+    Ws = rng.uniform(0.5, 0.95, ng)[sl]
+    u_expt = rng.uniform(8, 16, ng)[sl]
+    u_ksat = rng.uniform(100, 2000, ng)[sl]
+    u_quartz = rng.uniform(0.2, 0.8, ng)[sl]
+    u_bulk = rng.uniform(1400, 1600, ng)[sl]
+    avg_temp = rng.uniform(-3, 8, ng)[sl]
+    elevation = np.float32(rng.uniform(500, 2500, ng)).astype(float)[sl]
+    cell_offset_T = rng.uniform(-3, 3, ng)[sl]
+    ncell = c1 - c0
+    d.ncell = ncell
+
     cp = np.zeros((abi.cp_nrow(Nn, Nb), ncell))
     # layer depths rounded to mm like read_soilparam.c's (float)(int)(x*1000+0.5)/1000
-    depth = np.stack([np.full(ncell, 0.1), rng.uniform(0.2, 0.5, ncell), rng.uniform(0.8, 2.0, ncell)])
+    depth = np.stack([np.full(ncell, 0.1), u_d1, u_d2])
     depth = np.floor(depth * 1000 + 0.5) / 1000
-    b_infilt = rng.uniform(0.05, 0.4, ncell)
-    Ds = rng.uniform(0.001, 0.3, ncell)
-    Dsmax = rng.uniform(2, 30, ncell)
-    Ws = rng.uniform(0.5, 0.95, ncell)
-    expt = np.tile(rng.uniform(8, 16, ncell), (3, 1))
-    Ksat = np.tile(rng.uniform(100, 2000, ncell), (3, 1))
+    expt = np.tile(u_expt, (3, 1))
+    Ksat = np.tile(u_ksat, (3, 1))
     bubble = 0.32 * expt + 4.3
-    quartz = np.tile(rng.uniform(0.2, 0.8, ncell), (3, 1))
-    bulk = np.tile(rng.uniform(1400, 1600, ncell), (3, 1))
+    quartz = np.tile(u_quartz, (3, 1))
+    bulk = np.tile(u_bulk, (3, 1))
     soil_dens = np.full((3, ncell), 2650.0)
     organic = np.zeros((3, ncell))
     porosity = 1.0 - bulk / soil_dens                      # read_soilparam.c:900
@@ -266,10 +289,8 @@ def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, 
     Wpwp = 0.3 * max_moist                                 # :1030
     resid = np.full((3, ncell), 0.02)
     dp = np.full(ncell, 4.0)
-    avg_temp = rng.uniform(-3, 8, ncell)
-    elevation = np.float32(rng.uniform(500, 2500, ncell)).astype(float)
-    nlat = int(np.ceil(np.sqrt(ncell)))
-    lat = np.float32(45.0 + 0.0625 * (np.arange(ncell) // nlat)).astype(float)
+    nlat = int(np.ceil(np.sqrt(ncell_global)))
+    lat = np.float32(45.0 + 0.0625 * (np.arange(c0, c1) // nlat)).astype(float)
 
     cp[C["CP_DS"]] = Ds; cp[C["CP_DSMAX"]] = Dsmax; cp[C["CP_WS"]] = Ws; cp[C["CP_C"]] = 2.0
     cp[C["CP_B_INFILT"]] = b_infilt; cp[C["CP_DP"]] = dp; cp[C["CP_AVG_TEMP"]] = avg_temp
@@ -384,7 +405,7 @@ def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, 
     d.cell_hru_offset = np.ascontiguousarray((np.arange(ncell + 1) * nslot).astype(np.int32))
     d.cell_hru_list = np.ascontiguousarray((np.arange(nslot)[None, :] * ncell + cells[:, None]).reshape(-1).astype(np.int32))
     d.elevation = elevation
-    d.cell_offset_T = rng.uniform(-3, 3, ncell)
+    d.cell_offset_T = cell_offset_T
     d.rng_seed = seed
     return d
 
@@ -457,7 +478,8 @@ def make_forcing(d, step0, nsteps, start_doy=1, cold=0.0):
     min_tf = tf.min(axis=0)
     max_snow = d.cell_params[C["CP_MAX_SNOW_TEMP"]]
     min_rain = d.cell_params[C["CP_MIN_RAIN_TEMP"]]
-    cell_id = np.arange(nc, dtype=np.uint64)
+    # global cell numbers: a shard (make_domain(cell_range=...) / shard.shard_domain) draws the precipitation of ITS cells
+    cell_id = np.arange(nc, dtype=np.uint64) + np.uint64(getattr(d, "global_cell0", 0))
     for i in range(nsteps):
         s = step0 + i
         for j in range(NF):
