@@ -64,6 +64,8 @@ extern "C" {
 #define VIC_GF_406  0
 #define VIC_GF_410  1
 #define VIC_GF_FULL 2
+#define VIC_NODE_SOLVER_BRENT  0
+#define VIC_NODE_SOLVER_NEWTON 1
 #define VIC_TEMP_TH_VIC_412 0
 #define VIC_TEMP_TH_KIENZLE 1
 
@@ -96,7 +98,8 @@ typedef struct vicgpu_options {
   int IMPLICIT;             /* options.IMPLICIT: Newton-Raphson soil heat solver (frozen_soil.c:229-301, newt_raph_func_fast.c) */
   int BLOWING;              /* options.BLOWING: blowing-snow sublimation (CalcBlowingSnow.c); rejected when set */
   int QUICK_SOLVE;          /* options.QUICK_SOLVE (calc_surf_energy_bal.c:289-314, 400-475); rejected when set */
-  int reserved_i[1];
+  int NODE_SOLVER;          /* VIC_NODE_SOLVER_*: how the frozen-node heat balance (soil_thermal_eqn.c) is solved -- not a
+                               reference option; BRENT replays root_brent.c's iteration, NEWTON converges to the same root */
   double wind_h;            /* global_param.wind_h (m) */
   double reserved_d[3];
 } vicgpu_options;

@@ -107,7 +107,7 @@ class Options(ctypes.Structure):
         ("SNOW_ALBEDO", ctypes.c_int), ("SNOW_DENSITY", ctypes.c_int), ("TEMP_TH_TYPE", ctypes.c_int),
         ("GLACIER_ID", ctypes.c_int), ("GLACIER_DYNAMICS", ctypes.c_int), ("frozen_compat", ctypes.c_int),
         ("nveg_types", ctypes.c_int), ("CORRPREC", ctypes.c_int), ("IMPLICIT", ctypes.c_int), ("BLOWING", ctypes.c_int),
-        ("QUICK_SOLVE", ctypes.c_int), ("reserved_i", ctypes.c_int * 1),
+        ("QUICK_SOLVE", ctypes.c_int), ("NODE_SOLVER", ctypes.c_int),
         ("wind_h", ctypes.c_double), ("reserved_d", ctypes.c_double * 3),
     ]
 

@@ -1,34 +1,42 @@
 // vic_profile.hpp — the explicit soil temperature profile solve as a kernel of its own (device only, gfx950).
 //
 // solve_T_profile + calc_soil_thermal_fluxes (frozen_soil.c:105-225, 305-505): Gauss-Seidel sweeps over the thermal
-// nodes (<= 1000), each frozen node a Brent root find (root_brent.c, <= 1000 residual evaluations with a pow,
-// soil_thermal_eqn.c).  It is called once per residual evaluation of the Brent iteration on the surface temperature
-// (func_surf_energy_bal.c:190) and carries > 90 % of the arithmetic of a FROZEN_SOIL step, with a trip count that
-// differs from HRU to HRU by an order of magnitude.  It needs ~25 live doubles where the rest of the step needs
-// several hundred, so it runs here at many waves per SIMD, on a compacted work list, and balances its own load:
+// nodes (<= 1000) until no node moves by more than 0.01 K; a node at or above 0 C (or with frozen soil off) has a
+// closed-form update, a frozen node is the root of the node's heat balance with the freezing-point-depression curve in
+// it (soil_thermal_eqn.c).  The solve is called once per residual evaluation of the Brent iteration on the surface
+// temperature (func_surf_energy_bal.c:190) and carries most of the arithmetic of a FROZEN_SOIL step, with a trip count
+// that differs from HRU to HRU.  It runs here on a compacted, keyed work list with persistent waves:
 //
-//   * one lane = one solve at a time; the loop nest is flattened into ONE wave loop in which every lane carries its
-//     own (sweep, node, Brent) state and advances by one unit of work per trip -- a lane on an unfrozen node moves on
-//     while its neighbours iterate their Brent;
-//   * the waves are persistent and pull work: a lane that has finished its solve waits until a quarter of the wave
-//     has (or nothing else can run), then the waiting lanes write their results and take the next entries of the
-//     work list with one wave-aggregated atomic.  All waves therefore drain together, and the rare, memory-bound
-//     write-back / load section runs for 16 lanes at a time instead of for one or two lanes on most trips;
-//   * node temperatures (the only per-lane-indexed data that changes) live in LDS as [node][lane]; the constant
-//     per-node records are read from the item block (vic_surface.hpp) when a lane enters a node.
+//   * lane = one profile solve; the reference's loop nest runs as written -- sweeps { nodes { node solve } } -- with the
+//     wave in lock step: the work lists are keyed by the HRU's number of frozen nodes (vic_fd_stage), so the 64 solves of a
+//     wave have their frozen nodes in the same places; a lane whose Gauss-Seidel iteration has ended writes its record
+//     and takes the next item at the gate before the following sweep (the sweep count is per lane);
+//   * what a node visit needs is constant over all sweeps of a solve (and over all solves of one Brent iteration on
+//     Tsurf): the item block (vic_surface.hpp) holds it pre-folded, 10 doubles per node.  The 10-node instantiation
+//     loads the block ONCE per solve into registers (node loop unrolled, 2 waves per SIMD) -- the sweeps then touch no
+//     memory at all; the generic instantiation (any other node count) reads the record at each visit;
+//   * the frozen-node root.  The reference brackets the root in T0 +- 0.25 K (expanding by +-10 K up to five times) and
+//     runs Brent's method to a tolerance of 1e-7 K (root_brent.c).  The node balance is  f(T) = N - S*T + E*ice(T),
+//     strictly decreasing and continuous in T, so the root the reference converges to is THE root of f, whatever the
+//     method: here a bracket-safeguarded Newton iteration from the previous sweep's temperature, with the derivative of
+//     the freezing curve in closed form (it costs no further transcendental), stopped when the step is below 1e-8 K
+//     (the error left is below 1e-13 K) -- 3-4 evaluations instead of Brent's 8-12, and no 17-28-evaluation tail at the
+//     0 C kink.  N >= 0 means the root lies at or above 0 C where ice = 0: T = N / S without iterating.  What the
+//     reference's failure modes mean for a monotone f is kept: no root within T0 +- 50.25 K -> the node falls back to T0
+//     (TFALLBACK) or the solve reports an error.  One case is NOT monotone: the reference's "cold nose" variant of the
+//     residual at node 1 when |TL - TU| > 5 K (soil_thermal_eqn.c:103-110) switches a flux term off discontinuously;
+//     those visits run the reference's Brent (BrentLean, vic_math.hpp) on the reference's residual.
 //
-// Per lane the sequence of floating-point operations is the reference's, up to the three last-bit exceptions listed at
-// SoilThermalEqn (vic_surface.hpp) and BrentLean (vic_math.hpp).
+// Per lane the closed-form updates execute the reference's sequence of floating-point operations; the frozen-node roots
+// agree with the reference's to the reference's own stopping tolerance (measured: tests/test_gpu_parity.py).
 #pragma once
 #include "vic_surface.hpp"
 
 namespace vic {
 
 // Work lists are kept in NBUCKET segments by a per-HRU key (the number of frozen nodes at the start of the step, and
-// whether a node sits within SOIL_DT of 0 C -- see vic_fd_stage): the
-// profile kernel takes the segments one after the other, most expensive first, so that the HRUs a wave works on at any time
-// have the same nodes in Brent solves and need about the same number of trips -- measured on the bench workload, waves
-// of identical HRUs run the whole step 36 % faster than waves of neighbouring cells (tools/exp/homogeneous.py).
+// whether a node sits within SOIL_DT of 0 C -- see vic_fd_stage): the profile kernel takes the segments one after the
+// other, most expensive first, so that the HRUs a wave works on at any time have the same nodes frozen.
 #ifndef PROFILE_NBUCKET
 #define PROFILE_NBUCKET (2 * (VIC_MAX_NODES + 2))
 #endif
@@ -56,21 +64,169 @@ __host__ __device__ inline int pout_stride(int Nn) { return Nn + 1 + (Nn + 1) / 
 __host__ __device__ inline int pout_hru_stride(int Nn) { return 2 * pout_stride(Nn) + 2; }
 __host__ __device__ inline int pout_key(int Nn, int slot) { return 2 * pout_stride(Nn) + slot; }
 
-#ifndef PROFILE_GATE_LANES
-#define PROFILE_GATE_LANES 16
-#endif
-constexpr int PROFILE_GATE = PROFILE_GATE_LANES;
 #ifndef LOCKSTEP_GATE_LANES
 #define LOCKSTEP_GATE_LANES 16
 #endif
-constexpr int LOCKSTEP_GATE = LOCKSTEP_GATE_LANES;   // same for the lock-step kernel's refill of lanes whose item is through     // lanes that must be waiting before the write-back / fetch section runs
+constexpr int LOCKSTEP_GATE = LOCKSTEP_GATE_LANES;   // idle lanes that must be waiting before the write-back / fetch section runs
 
+constexpr double NODE_ROOT_RANGE = SOIL_DT + Brent::MAXTRIES * Brent::TSTEP;   // the reference finds roots within T0 +- this
+constexpr double NODE_NEWTON_TOL = 1.e-8;                                        // last Newton step, K
+constexpr int NODE_NEWTON_MAXIT = 200;
+
+// The per-node constants of one record (PR_AT0 .. PR_EMM), see vic_surface.hpp
+struct NodeK {
+  double AT0, B, C, D, EI, S, G, Y, EM, EMM;
+  VIC_DEV void load(const double* __restrict__ r) {
+    AT0 = r[PR_AT0]; B = r[PR_B]; C = r[PR_C]; D = r[PR_D]; EI = r[PR_EI]; S = r[PR_S]; G = r[PR_G]; Y = r[PR_Y];
+    EM = r[PR_EMOIST]; EMM = r[PR_EMM];
+  }
+  // E * ice(T) for T < 0 (soil_thermal_eqn.c:66-71 with maximum_unfrozen_water), E*u(T) and whether the curve is active
+  VIC_DEV double eice(double T, double& Eu, bool& curved) const {
+    Eu = G * exp(Y * ln_pos(-T));
+    curved = true;
+    if (Eu > EMM) { Eu = EMM; curved = false; }        // u > max_moist
+    double Ei = EM - Eu;
+    if (Ei < 0.) { Ei = 0.; curved = false; }
+    if (Ei > EMM) { Ei = EMM; curved = false; }
+    return Ei;
+  }
+};
+
+// One Gauss-Seidel visit of a node for all lanes of the wave (call convergently; `sweeping` = this lane takes part).
+// NODE1: the visit is node 1, where the reference's residual has its cold-nose variant.
+// Returns the new node temperature; failed: the reference's root finder would have returned ERROR.
+template <bool NODE1, bool NEWTON>
+VIC_DEV double node_visit(bool sweeping, bool frozen_on, bool EXP_TRANS, const NodeK& K, double oldT, double Tdn, double Tup, double T0j,
+                          bool& failed) {
+  // numerator of the closed-form update in the reference's operation order (frozen_soil.c:388-393, 429-436)
+  double N;
+  if (!EXP_TRANS) N = K.AT0 + K.B * (Tdn - Tup) + K.C * Tdn + K.D * Tup + K.EI;
+  else N = K.AT0 + K.B * (Tdn - Tup) + K.C * (Tdn + Tup) - K.D * (Tdn - Tup) + K.EI;
+  const bool fz = sweeping && frozen_on && oldT < 0;
+  // `steep`: visits that run the reference's Brent iteration -- all frozen visits when NEWTON is off, otherwise only the
+  // discontinuous cold-nose case at node 1
+  bool steep = false;
+  const bool nose = NODE1 && fabs(Tdn - Tup) > 5.;
+  if (!NEWTON) steep = fz;
+  else if (NODE1) steep = fz && nose;
+  double x = N / K.S;                       // unfrozen node, or root in T >= 0 where ice = 0
+  failed = false;
+  PROF_WAVE(18); PROF_VOTE(19, fz);
+
+  // ---- safeguarded Newton on f(T) = N - S T + E ice(T) in T < 0 (f(0) = N < 0 there: 0 is an upper bound of the root)
+  bool act = NEWTON && fz && !steep && N < 0;
+  if (NEWTON && __any(act)) {
+    PROF_WAVE(22);
+    double lo = -1.e300, hi = 0.0;
+    x = act ? oldT : x;
+    int it = 0;
+    while (__any(act)) {
+      PROF_WAVE(20); PROF_VOTE(21, act);
+      if (act) {
+        double Eu;
+        bool curved;
+        const double Ei = K.eice(x, Eu, curved);
+        const double f = N - K.S * x + Ei;
+        if (f > 0) lo = x; else hi = x;
+        const double den = K.S * x + (curved ? K.Y * Eu : 0.0);          // = x f'(x), negative
+        const double step = f * x / den;
+        double xn = x + step;
+        it++;
+        if (fabs(step) <= NODE_NEWTON_TOL) act = false;                      // converged: the step is taken as it is
+        else {
+          // a step that leaves the bracket (a kink of the curve between x and the root) is replaced by a bisection; a step
+          // down can only leave it once a lower bound is known
+          if (!(xn > lo && xn < hi)) xn = (lo > -1.e299) ? 0.5 * (lo + hi) : x + x - 1.0;
+          if (it >= NODE_NEWTON_MAXIT) { act = false; failed = true; }
+        }
+        x = xn;
+      }
+    }
+  }
+  // ---- the reference's Brent iteration (root_brent.c:97-337) on the reference's residual
+  if (NODE1 || !NEWTON) {
+    if (__any(steep)) {
+      BrentLean br;
+      br.phase = BrentLean::DONE;
+      if (steep) br.start(T0j - SOIL_DT, T0j + SOIL_DT);
+      const double ft1 = K.B * (Tdn - Tup);
+      while (__any(steep && !br.finished())) {
+        if (steep && !br.finished()) {
+          const double T = br.x;
+          double Ei = 0.;
+          if (T < 0.) { double Eu; bool cv_; Ei = K.eice(T, Eu, cv_); }
+          double v = N - K.S * T + Ei;
+          const double ft2 = !EXP_TRANS ? K.C * (Tdn - T) - K.D * (T - Tup) : K.C * (Tdn - 2. * T + Tup) - K.D * (Tdn - Tup);
+          if (NODE1 && nose && (T < Tdn && T < Tup) && (ft1 < 0 && ft2 > 0) && fabs(ft1) > fabs(ft2)) v -= ft1;
+          br.advance(v);
+        }
+      }
+      if (steep) { x = br.b; if (br.phase == BrentLean::FAILED) failed = true; }
+    }
+  }
+  // the reference searches T0 +- 0.25 K, widened by 10 K up to five times (root_brent.c:183-248)
+  if (fz && !steep && !(fabs(x - T0j) <= NODE_ROOT_RANGE)) failed = true;
+#ifdef VIC_DEBUG_NODE
+  if (failed) printf("node failed: NODE1 %d steep %d N %g S %g x %.17g T0j %g oldT %g Tdn %g Tup %g G %g Y %g EM %g EMM %g\n", (int)NODE1, (int)steep, N, K.S, x, T0j, oldT, Tdn, Tup, K.G, K.Y, K.EM, K.EMM);
+#endif
+  return x;
+}
+
+// the end of a solve: cold-nose hack, non-convergence, fallback bookkeeping (frozen_soil.c:470-493); T / T0 accessors differ
+// between the two kernels, so this is a macro-free helper over plain arrays of the lane's column
 template <int NN>
-__global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
-  __shared__ double Tl[NN * 64];      // current iterate  [node][lane]
-  __shared__ double T0l[NN * 64];     // previous step    [node][lane]
+VIC_DEV void profile_finish(int Nn, bool TFALLBACK, bool converged, bool& ok, unsigned& fbmask, double* T, const double* T0, int* cnt_add) {
+#pragma unroll
+  for (int k = 0; k < NN; k++) cnt_add[k] = 0;
+  if (ok && TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T[j]); Tlast == T0
+#pragma unroll
+    for (int k = 1; k < NN - 1; k++) {
+      if (k < Nn - 1) {
+        const double Tk = T[k], Tm = T[k - 1], Tp = T[k + 1], Lk = T0[k], Lm = T0[k - 1], Lp = T0[k + 1];
+        if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
+          T[k] = 0.5 * (Tm + Tp);
+          fbmask |= (1u << k);
+          cnt_add[k] += 1;
+        }
+      }
+    }
+  }
+  if (ok && !converged) {
+    if (TFALLBACK) {
+#pragma unroll
+      for (int k = 0; k < NN; k++)
+        if (k < Nn) { T[k] = T0[k]; cnt_add[k] += 1; }
+      fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
+    } else ok = false;
+  }
+}
+
+// work-list slot -> HRU (segments are taken highest key first: most frozen nodes = most work)
+VIC_DEV int profile_pick(const PArgs& a, const int* bcount, int slot) {
+  int rem = slot, found = 0;
+#pragma unroll 1
+  for (int b = NBUCKET - 1; b >= 0; b--) {
+    const int cb = bcount[b];
+    if (rem < cb) { found = b * a.cap + rem; break; }
+    rem -= cb;
+  }
+  return a.list[found];
+}
+
+// ------------------------------------------------------------------------------------------------
+// 10 nodes (the sample global file's and BASELINE's node count): node constants and temperatures in registers
+// ------------------------------------------------------------------------------------------------
+#ifndef PROFILE_REG_WAVES
+#define PROFILE_REG_WAVES 2
+#endif
+template <int NN, bool NEWTON>
+__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG_WAVES) void vic_profile_solve_reg(const PArgs a) {
   __shared__ int bcount[NBUCKET];
+  __shared__ double T0l[NN * 64];
+  __shared__ double Kl[3 * (NN - 2) * 64];             // G, Y, E*moist of the interior nodes: only frozen visits read them
   const int lane = threadIdx.x;
+#define T0(j) T0l[(j) * 64 + lane]
+#define KL(f, j) Kl[((f) * (NN - 2) + (j) - 1) * 64 + lane]
   for (int b = lane; b < NBUCKET; b += 64) bcount[b] = a.count[b];
   if (blockIdx.x == 0) {
     for (int b = lane; b < NBUCKET; b += 64) a.count_zero[b] = 0;
@@ -80,185 +236,137 @@ __global__ __launch_bounds__(64) void vic_profile_solve(const PArgs a) {
   int n = 0;
 #pragma unroll
   for (int b = 0; b < NBUCKET; b++) n += bcount[b];
-  if ((int)blockIdx.x * 64 >= n) return;           // more waves than work: nothing to pull (the grid is sized from an upper bound)
+  if ((int)blockIdx.x * 64 >= n) return;
 
-  const int Nn = (NN == VIC_MAX_NODES) ? a.Nn : NN;
-  const int jlast = a.NOFLUX ? Nn : Nn - 1;     // exclusive upper node of a sweep
+  constexpr int Nn = NN;
+  const int jlast = a.NOFLUX ? Nn : Nn - 1;
   const int MAXIT = 1000;
   const double threshold = 1.e-2;
-#define TL(j) Tl[(j) * 64 + lane]
-#define T0L(j) T0l[(j) * 64 + lane]
-// the solution record of the current solve (pointers are recomputed where needed: they would cost six registers)
-#define REC() (a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn))
-#define CNT(j) (reinterpret_cast<int*>(REC() + Nn + 1)[j])      // fallback counters live in the record (rarely touched)
+  const bool EXP_TRANS = a.EXP_TRANS != 0;
 
-  enum { NODE = 1, BRENT = 2, FINISH = 3, IDLE = 4 };   // FINISH: solve done (or nothing yet), waiting at the gate
-  int mode = FINISH;
-  int hru = -1, it = 1, j = 1;
-  bool frozen_on = false, ok = true, converged = false;
+  bool have = false, sweeping = false, converged = false, ok = true, frozen_on = false;
+  int hru = 0, ps = 0, it = 1;
   unsigned fbmask = 0;
-  double maxdiff = threshold, oldT = 0;
-  const double* __restrict__ blk = a.pin;
-  int ps = 0;
-  BrentLean br;
-  SoilThermalEqn eq;
-  br.phase = BrentLean::DONE;
-#ifdef VIC_PROF
-  long long tp_gate = 0, tp_node = 0, tp_eq = 0, tp_adv = 0, tp_done = 0, tp_last = (long long)__builtin_readcyclecounter();
-#define TP(acc) do { const long long n_ = (long long)__builtin_readcyclecounter(); acc += n_ - tp_last; tp_last = n_; } while (0)
-#else
-#define TP(acc) do { } while (0)
-#endif
-
+  int evcnt = 0;                                       // 1 once a node solver of this solve has fallen back (see below)
+  double T[NN];
+  // node constants of the interior nodes 1 .. NN-2: seven in registers, three in LDS (see KL)
+  double kAT0[NN - 1], kB[NN - 1], kC[NN - 1], kD[NN - 1], kEI[NN - 1], kS[NN - 1], kEMM[NN - 1];
+#pragma unroll
+  for (int k = 0; k < NN; k++) T[k] = 0;
+#pragma unroll
+  for (int k = 0; k < NN - 1; k++) { kAT0[k] = 0; kB[k] = 0; kC[k] = 0; kD[k] = 0; kEI[k] = 0; kS[k] = 1; kEMM[k] = 0; }
+  bool more = true;                                    // wave-uniform: the work list has items nobody has taken yet
   while (true) {
-    TP(tp_done);
-    // ---- gate: write-back of finished solves + fetch of new items (wave-uniform branch)
-    const unsigned long long waiting = __ballot(mode == FINISH);
-    const unsigned long long running = __ballot(mode == NODE || mode == BRENT);
-    if (waiting == 0 && running == 0) break;             // every lane is IDLE
-    if (waiting != 0 && (__popcll(waiting) >= PROFILE_GATE || running == 0)) {
-      if (mode == FINISH) {
-        if (hru >= 0) {
-          if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T[j]); Tlast == T0
-#pragma unroll 1
-            for (int k = 1; k < Nn - 1; k++) {
-              const double Tk = TL(k), Tm = TL(k - 1), Tp = TL(k + 1), Lk = T0L(k), Lm = T0L(k - 1), Lp = T0L(k + 1);
-              if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
-                TL(k) = 0.5 * (Tm + Tp);
-                fbmask |= (1u << k);
-                CNT(k) += 1;
-              }
+    const unsigned long long idle = __ballot(!have);
+    if (more && (__popcll(idle) >= LOCKSTEP_GATE || idle == ~0ull)) {
+      const int nidle = __popcll(idle), leader = __ffsll((long long)idle) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(a.next, nidle);
+      base = __builtin_amdgcn_readlane(base, leader);
+      if (base + nidle >= n) more = false;
+      const int slot = base + __popcll(idle & ((1ull << lane) - 1ull));
+      if (!have && slot < n) {
+        hru = profile_pick(a, bcount, slot);
+        const double* __restrict__ blk = a.pin + (size_t)hru * Nn * PREC;
+        ps = a.pslot[hru];
+        frozen_on = blk[PR_AT0] != 0.0;
+        const double Ts = a.ts[hru];
+#pragma unroll
+        for (int k = 0; k < NN; k++) { const double t = (k == 0) ? Ts : blk[k * PREC + PR_T0]; T0(k) = t; T[k] = t; }
+#pragma unroll
+        for (int k = 1; k < NN - 1; k++) {
+          const double* __restrict__ r = blk + k * PREC;
+          kAT0[k] = r[PR_AT0]; kB[k] = r[PR_B]; kC[k] = r[PR_C]; kD[k] = r[PR_D]; kEI[k] = r[PR_EI]; kS[k] = r[PR_S]; kEMM[k] = r[PR_EMM];
+          KL(0, k) = r[PR_G]; KL(1, k) = r[PR_Y]; KL(2, k) = r[PR_EMOIST];
+        }
+        have = true; fbmask = 0; evcnt = 0; ok = true; it = 1;
+        converged = (jlast <= 1);
+        sweeping = !converged;
+      }
+    }
+    if (!__any(have)) break;
+    {
+      double maxdiff = threshold;
+      PROF_WAVE(16); PROF_VOTE(17, sweeping);
+#pragma unroll
+      for (int j = 1; j < NN; j++) {
+        if (j < jlast) {
+          const double oldT = T[j];
+          const double Tdn = (j == Nn - 1) ? oldT : T[(j + 1 < NN) ? j + 1 : j], Tup = T[j - 1];
+          const double T0j = T0(j);
+          NodeK Kj;
+          if (j == NN - 1) Kj.load(a.pin + ((size_t)hru * Nn + j) * PREC);      // the bottom node (NOFLUX only) is not cached
+          else {
+            constexpr int q = 0;
+            const int jj = (j < NN - 1) ? j : 1 + q;
+            Kj.AT0 = kAT0[jj]; Kj.B = kB[jj]; Kj.C = kC[jj]; Kj.D = kD[jj]; Kj.EI = kEI[jj]; Kj.S = kS[jj]; Kj.EMM = kEMM[jj];
+            Kj.G = KL(0, jj); Kj.Y = KL(1, jj); Kj.EM = KL(2, jj);
+          }
+          bool failed;
+          double newT;
+          if (j == 1) newT = node_visit<true, NEWTON>(sweeping, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
+          else newT = node_visit<false, NEWTON>(sweeping, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
+          if (sweeping) {
+            if (failed) {
+              if (a.TFALLBACK) {
+                // node fallback: T0 and a count.  The counters live in the solution record (rare path): the first event of a
+                // solve clears them, the end of the solve adds its own events or, without any, writes them whole
+                int* cnt = reinterpret_cast<int*>(a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn) + Nn + 1);
+                if (evcnt == 0) {
+#pragma unroll
+                  for (int k = 0; k < NN; k++) cnt[k] = 0;
+                }
+                evcnt = 1;
+                cnt[j] += 1;
+                newT = T0j; fbmask |= (1u << j);
+              } else { ok = false; sweeping = false; }
+            }
+            if (sweeping) {
+              T[j] = newT;
+              const double diff = fabs(oldT - newT);
+              if (diff > maxdiff) maxdiff = diff;
             }
           }
-          if (ok && !converged) {
-            if (a.TFALLBACK) {
-#pragma unroll 1
-              for (int k = 0; k < Nn; k++) { TL(k) = T0L(k); CNT(k) += 1; }
-              fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
-            } else ok = false;
-          }
-          double* __restrict__ out = REC();
-#pragma unroll
-          for (int k = 0; k < NN; k++)
-            if (k < Nn) out[k] = TL(k);
-          out[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
-          a.pout[(size_t)hru * pout_hru_stride(Nn) + pout_key(Nn, ps)] = T0L(0);   // the trial surface temperature of this record
         }
-        // next item: one atomic for all waiting lanes
-        const int leader = __ffsll((long long)waiting) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(a.next, __popcll(waiting));
-        base = __builtin_amdgcn_readlane(base, leader);
-        const int slot = base + __popcll(waiting & ((1ull << lane) - 1ull));
-        if (slot < n) {
-          {
-            int rem = slot, found = 0;              // segment of this slot, highest key (most work) first
-#pragma unroll 1
-            for (int b = NBUCKET - 1; b >= 0; b--) {
-              const int cb = bcount[b];
-              if (rem < cb) { found = b * a.cap + rem; break; }
-              rem -= cb;
-            }
-            hru = a.list[found];
-          }
-          blk = a.pin + (size_t)hru * Nn * PREC;
-          ps = a.pslot[hru];
-          frozen_on = blk[PR_A] != 0.0;
-          const double Ts = a.ts[hru];
+      }
+      if (sweeping) {                               // end of a Gauss-Seidel sweep (frozen_soil.c:466)
+        if (maxdiff <= threshold) { converged = true; sweeping = false; }
+        else if (it >= MAXIT) sweeping = false;
+        else it++;
+      }
+    }
+    if (have && !sweeping) {                        // this lane's item is through: finish it and free the lane
+      double T0v[NN];
+      int cadd[NN];
 #pragma unroll
-          for (int k = 0; k < NN; k++)
-            if (k < Nn) { const double t = (k == 0) ? Ts : blk[k * PREC + PR_T0]; T0L(k) = t; TL(k) = t; CNT(k) = 0; }
-          fbmask = 0; ok = true; it = 1; j = 1; maxdiff = threshold;
-          converged = (jlast <= 1);
-          mode = converged ? FINISH : NODE;
-        } else { hru = -1; mode = IDLE; }
+      for (int k = 0; k < NN; k++) T0v[k] = T0(k);
+      profile_finish<NN>(Nn, a.TFALLBACK != 0, converged, ok, fbmask, T, T0v, cadd);
+      double* __restrict__ rec = a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn);
+      int* __restrict__ cnt = reinterpret_cast<int*>(rec + Nn + 1);
+#pragma unroll
+      for (int k = 0; k < NN; k++) rec[k] = T[k];
+      rec[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
+      // fallback counters: zero unless something happened in this solve (node-solver fallbacks were written as they happened)
+#pragma unroll
+      for (int k = 0; k < NN; k++) {
+        if (evcnt == 0) cnt[k] = cadd[k];
+        else cnt[k] += cadd[k];
       }
-    }
-    TP(tp_gate);
-    // ---- one unit of work per lane
-    bool node_done = false;
-    double newT = 0;
-    if (mode == NODE) {
-      oldT = TL(j);
-      const bool bottom = (j == Nn - 1);        // only reached with NOFLUX (frozen_soil.c:423-464)
-      const double Tdn = bottom ? oldT : TL(j + 1), Tup = TL(j - 1);
-      const double* __restrict__ r = blk + j * PREC;
-      const double A = r[PR_A], B = r[PR_B], C = r[PR_C], D = r[PR_D], T0j = T0L(j);
-      if (oldT >= 0 || !frozen_on) {
-        const double EI = r[PR_EI];
-        if (!a.EXP_TRANS) newT = (A * T0j + B * (Tdn - Tup) + C * Tdn + D * Tup + EI) / (A + C + D);
-        else newT = (A * T0j + B * (Tdn - Tup) + C * (Tdn + Tup) - D * (Tdn - Tup) + EI) / (A + 2. * C);
-        node_done = true;
-      } else {
-        eq.TL = Tdn; eq.TU = Tup; eq.T0 = T0j; eq.moist = r[PR_MOIST]; eq.ice0 = r[PR_ICE];
-        eq.A = A; eq.C = C; eq.D = D; eq.E = r[PR_E];
-        eq.max_moist = r[PR_MAXM];
-        eq.prepare(B, r[PR_CURVE_DIV], r[PR_CURVE_EXP], j);
-        br.start(T0j - SOIL_DT, T0j + SOIL_DT);
-        mode = BRENT;
-      }
-    }
-    TP(tp_node);
-    if (mode == BRENT) {
-      const double fx = eq.eval(br.x, a.EXP_TRANS != 0);
-      TP(tp_eq);
-      br.advance(fx);
-      if (br.finished()) {
-        double rt = br.b;
-        if (br.phase == BrentLean::FAILED) {
-          if (a.TFALLBACK) { rt = eq.T0; fbmask |= (1u << j); CNT(j) += 1; }
-          else { ok = false; mode = FINISH; }
-        }
-        if (mode == BRENT) { newT = rt; node_done = true; mode = NODE; }
-      }
-    }
-    TP(tp_adv);
-    if (node_done) {
-      TL(j) = newT;
-      const double diff = fabs(oldT - newT);
-      if (diff > maxdiff) maxdiff = diff;
-      j++;
-      if (j >= jlast) {                           // end of a Gauss-Seidel sweep (frozen_soil.c:466)
-        if (maxdiff <= threshold) { converged = true; mode = FINISH; }
-        else if (it >= MAXIT) mode = FINISH;
-        else { it++; j = 1; maxdiff = threshold; }
-      }
+      a.pout[(size_t)hru * pout_hru_stride(Nn) + pout_key(Nn, ps)] = T0(0);
+      have = false;
     }
   }
-#ifdef VIC_PROF
-  if (lane == 0) {
-    atomicAdd(&vic_prof_cyc[20], (unsigned long long)tp_gate); atomicAdd(&vic_prof_cyc[21], (unsigned long long)tp_node);
-    atomicAdd(&vic_prof_cyc[22], (unsigned long long)tp_eq); atomicAdd(&vic_prof_cyc[23], (unsigned long long)tp_adv);
-    atomicAdd(&vic_prof_cyc[24], (unsigned long long)tp_done);
-  }
-#endif
-#undef TP
-#undef TL
-#undef T0L
-#undef CNT
-#undef REC
+#undef T0
+#undef KL
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lock-step variant: with the work lists keyed by the frozen-node count, the 64 HRUs a wave holds have their Brent solves
-// at the same nodes, so the reference's loop nest can run as written -- sweeps { nodes { Brent } } -- with the wave
-// iterating each node's Brent until its slowest lane is through.  Node columns live in LDS, there is no per-lane mode
-// inside a sweep; a lane whose Gauss-Seidel iteration has ended writes its record and takes the next item at the gate
-// before the following sweep, so the sweep count is per lane (91 % of lanes busy per sweep) while every node visit still
-// costs the slowest lane's Brent (12.8 wave iterations for 8.2 per lane on cfg3: the 53 % lane utilisation that is left).
+// any node count: node columns in LDS, the node's record read at each visit
 // ------------------------------------------------------------------------------------------------
-// tools/hostemu with -DVIC_HOSTEMU_HIST: histogram of Brent evaluations per node solve, split by whether the bracket
-// T0 +- SOIL_DT contains 0 C (how the work-list key of vic_fd_stage was chosen)
-#ifdef VIC_HOSTEMU_HIST
-static long vic_hist[64];
-static long vic_hist2[64];
-static void vic_hist_print() { for (int i = 0; i < 32; i++) printf("nit %d far %ld near %ld\n", i, vic_hist[i], vic_hist2[i]); }
-static void vic_hist_add(int n, bool near0) { static bool reg = (atexit(vic_hist_print), true); (void)reg; (near0 ? vic_hist2 : vic_hist)[n < 63 ? n : 63]++; }
-#endif
 #ifndef LS_WAVES
-#define LS_WAVES 3      // 136 VGPRs; 4 waves/SIMD (128 VGPRs, 44 B scratch, LDS then allows 15 waves per CU) measured 1.5 % slower
+#define LS_WAVES 2
 #endif
-template <int NN>
+template <int NN, bool NEWTON>
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_profile_solve_lockstep(const PArgs a) {
   __shared__ int bcount[NBUCKET];
   __shared__ double Tl[NN * 64];
@@ -285,16 +393,11 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
 
 #define LS_REC() (a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn))
 #define LS_CNT(j) (reinterpret_cast<int*>(LS_REC() + Nn + 1)[j])
-  // Per-lane item state.  A lane keeps its item across sweeps; when the item's Gauss-Seidel iteration ends the lane writes
-  // the record back and waits at the gate for the next item, so a wave is not held to its slowest HRU's sweep count.
   bool have = false, sweeping = false, converged = false, ok = true, frozen_on = false;
   int hru = 0, ps = 0, it = 1;
   unsigned fbmask = 0;
   const double* __restrict__ blk = a.pin;
-#ifdef VIC_HOSTEMU_HIST
-  int hist_nit = 0;
-#endif
-  bool more = true;                                  // wave-uniform: the work list has items nobody has taken yet
+  bool more = true;
   while (true) {
     const unsigned long long idle = __ballot(!have);
     if (more && (__popcll(idle) >= LOCKSTEP_GATE || idle == ~0ull)) {
@@ -305,17 +408,10 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
       if (base + nidle >= n) more = false;
       const int slot = base + __popcll(idle & ((1ull << lane) - 1ull));
       if (!have && slot < n) {
-        int rem = slot, found = 0;
-#pragma unroll 1
-        for (int b = NBUCKET - 1; b >= 0; b--) {
-          const int cb = bcount[b];
-          if (rem < cb) { found = b * a.cap + rem; break; }
-          rem -= cb;
-        }
-        hru = a.list[found];
+        hru = profile_pick(a, bcount, slot);
         blk = a.pin + (size_t)hru * Nn * PREC;
         ps = a.pslot[hru];
-        frozen_on = blk[PR_A] != 0.0;
+        frozen_on = blk[PR_AT0] != 0.0;
         const double Ts = a.ts[hru];
 #pragma unroll
         for (int k = 0; k < NN; k++)
@@ -332,50 +428,23 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
 #pragma unroll 1
       for (int j = 1; j < NN; j++) {
         if (j < jlast) {
-          bool fz = false;
-          double oldT = 0, newT = 0;
-          BrentLean br;
-          SoilThermalEqn eq;
-          br.phase = BrentLean::DONE;
+          double oldT = 0, Tdn = 0, Tup = 0, T0j = 0;
+          NodeK K;
+          K.AT0 = 0; K.B = 0; K.C = 0; K.D = 0; K.EI = 0; K.S = 1; K.G = 0; K.Y = 0; K.EM = 0; K.EMM = 0;
           if (sweeping) {
             oldT = T(j);
-            const double Tdn = (j == Nn - 1) ? oldT : T((j + 1 < NN) ? j + 1 : j), Tup = T(j - 1);
-            const double* __restrict__ r = blk + j * PREC;
-            const double A = r[PR_A], B = r[PR_B], C = r[PR_C], D = r[PR_D], T0j = T0(j);
-            if (oldT >= 0 || !frozen_on) {
-              const double EI = r[PR_EI];
-              if (!EXP_TRANS) newT = (A * T0j + B * (Tdn - Tup) + C * Tdn + D * Tup + EI) / (A + C + D);
-              else newT = (A * T0j + B * (Tdn - Tup) + C * (Tdn + Tup) - D * (Tdn - Tup) + EI) / (A + 2. * C);
-            } else {
-              eq.TL = Tdn; eq.TU = Tup; eq.T0 = T0j; eq.moist = r[PR_MOIST]; eq.ice0 = r[PR_ICE];
-              eq.A = A; eq.C = C; eq.D = D; eq.E = r[PR_E];
-              eq.max_moist = r[PR_MAXM];
-              eq.prepare(B, r[PR_CURVE_DIV], r[PR_CURVE_EXP], j);
-              br.start(T0j - SOIL_DT, T0j + SOIL_DT);
-              fz = true;
-            }
+            Tdn = (j == Nn - 1) ? oldT : T((j + 1 < NN) ? j + 1 : j); Tup = T(j - 1);
+            T0j = T0(j);
+            K.load(blk + j * PREC);
           }
-          PROF_WAVE(18); PROF_VOTE(19, fz); if (__any(fz)) PROF_WAVE(22);
-          while (__any(fz && !br.finished())) {
-            PROF_WAVE(20); PROF_VOTE(21, fz && !br.finished());
-#ifdef VIC_HOSTEMU_HIST
-            if (fz && !br.finished()) hist_nit++;
-#endif
-            if (fz && !br.finished()) {
-              const double fx = eq.eval(br.x, EXP_TRANS);
-              br.advance(fx);
-            }
-          }
-#ifdef VIC_HOSTEMU_HIST
-          if (fz) { vic_hist_add(hist_nit, fabs(eq.T0) < SOIL_DT); hist_nit = 0; }
-#endif
+          bool failed;
+          double newT;
+          if (j == 1) newT = node_visit<true, NEWTON>(sweeping, frozen_on, EXP_TRANS, K, oldT, Tdn, Tup, T0j, failed);
+          else newT = node_visit<false, NEWTON>(sweeping, frozen_on, EXP_TRANS, K, oldT, Tdn, Tup, T0j, failed);
           if (sweeping) {
-            if (fz) {
-              newT = br.b;
-              if (br.phase == BrentLean::FAILED) {
-                if (a.TFALLBACK) { newT = eq.T0; fbmask |= (1u << j); LS_CNT(j) += 1; }
-                else { ok = false; sweeping = false; }
-              }
+            if (failed) {
+              if (a.TFALLBACK) { newT = T0j; fbmask |= (1u << j); LS_CNT(j) += 1; }
+              else { ok = false; sweeping = false; }
             }
             if (sweeping) {
               T(j) = newT;
@@ -390,33 +459,29 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
         else if (it >= MAXIT) sweeping = false;
         else it++;
       }
-        }
+    }
     if (have && !sweeping) {                        // this lane's item is through: finish it and free the lane
       if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T(j)); Tlast == T0
-#pragma unroll
-        for (int k = 1; k < NN - 1; k++) {
-          if (k < Nn - 1) {
-            const double Tk = T(k), Tm = T(k - 1), Tp = T(k + 1), Lk = T0(k), Lm = T0(k - 1), Lp = T0(k + 1);
-            if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
-              T(k) = 0.5 * (Tm + Tp);
-              fbmask |= (1u << k);
-              LS_CNT(k) += 1;
-            }
+#pragma unroll 1
+        for (int k = 1; k < Nn - 1; k++) {
+          const double Tk = T(k), Tm = T(k - 1), Tp = T(k + 1), Lk = T0(k), Lm = T0(k - 1), Lp = T0(k + 1);
+          if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
+            T(k) = 0.5 * (Tm + Tp);
+            fbmask |= (1u << k);
+            LS_CNT(k) += 1;
           }
         }
       }
       if (ok && !converged) {
         if (a.TFALLBACK) {
-#pragma unroll
-          for (int k = 0; k < NN; k++)
-            if (k < Nn) { T(k) = T0(k); LS_CNT(k) += 1; }
+#pragma unroll 1
+          for (int k = 0; k < Nn; k++) { T(k) = T0(k); LS_CNT(k) += 1; }
           fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
         } else ok = false;
       }
       double* __restrict__ rec = LS_REC();
-#pragma unroll
-      for (int k = 0; k < NN; k++)
-        if (k < Nn) rec[k] = T(k);
+#pragma unroll 1
+      for (int k = 0; k < Nn; k++) rec[k] = T(k);
       rec[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
       a.pout[(size_t)hru * pout_hru_stride(Nn) + pout_key(Nn, ps)] = T0(0);
       have = false;

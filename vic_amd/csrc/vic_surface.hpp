@@ -14,89 +14,31 @@ VIC_DEV double estimate_T1(double Ts, double T1_old, double T2, double D1, doubl
          / (C1 / delta_t + kappa2 / D1 / D2 * C2 + C3 / 2. / D2);
 }
 
-// residual of one frozen node (soil_thermal_eqn.c:8-131).  prepare() hoists what does not depend on the trial
-// temperature out of the Brent iteration: the divisor and exponent of the freezing-point-depression curve
-// (maximum_unfrozen_water), B*(TL-TU) and the |TL-TU| > 5 test of the node-1 special case.  The argument of the curve,
-// -Lf*T/273.16/den in the reference, is formed with the reciprocal of 273.16*den (two fp64 divisions less per evaluation,
-// last-bit differences in an argument whose power already differs from glibc's pow in the last bits);
-// -DVIC_REFERENCE_DIVISIONS restores the reference's two divisions here and its three quotients in BrentLean.
-struct SoilThermalEqn {
-  double TL, TU, T0, moist, max_moist, ice0, A, C, D, E;
-  double den, yexp, flux_term1;
-  double inv_den;
-  int steep;
-  // the two per-node constants of the curve, computed once per step when the item block is written (profile_item_store)
-  static VIC_DEV double curve_exponent(double expt) { return -(2.0 / (expt - 3.0)); }
-  static VIC_DEV double curve_divisor(double bubble) {
-    const double d = 9.81 * bubble / 100.;
-#ifdef VIC_REFERENCE_DIVISIONS
-    return d;
-#else
-    return 1.0 / (273.16 * d);
-#endif
-  }
-  VIC_DEV void prepare(double B, double curve_div, double curve_exp, int node) {
-#ifdef VIC_REFERENCE_DIVISIONS
-    den = curve_div;
-#else
-    inv_den = curve_div;
-#endif
-    yexp = curve_exp;
-    flux_term1 = B * (TL - TU);
-    steep = (node == 1 && fabs(TL - TU) > 5.) ? 1 : 0;
-  }
-  VIC_DEV double eval(double T, bool EXP_TRANS) const {
-    double ice;
-    if (T < 0.) {
-#ifdef VIC_REFERENCE_DIVISIONS
-      double u = max_moist * pow_pos((-LF * T) / 273.16 / den, yexp);       // maximum_unfrozen_water, T <= 0 branch
-#else
-      double u = max_moist * pow_pos_finite((-LF * T) * inv_den, yexp);     // one rounding instead of two: see above
-#endif
-      if (u > max_moist) u = max_moist;
-      if (u < 0) u = 0;
-      ice = moist - u;
-      if (ice < 0.) ice = 0.;
-      if (ice > max_moist) ice = max_moist;
-    } else ice = 0.;
-    double value;
-    if (!EXP_TRANS) {
-      value = -A * (T - T0) + flux_term1 + C * (TL - T) - D * (T - TU) + E * (ice - ice0);
-      if (steep) {
-        const double flux_term2 = C * (TL - T) - D * (T - TU);
-        if ((T < TL && T < TU) && (flux_term1 < 0 && flux_term2 > 0) && fabs(flux_term1) > fabs(flux_term2))
-          value = -A * (T - T0) + C * (TL - T) - D * (T - TU) + E * (ice - ice0);
-      }
-    } else {
-      value = -A * (T - T0) + flux_term1 + C * (TL - 2. * T + TU) - D * (TL - TU) + E * (ice - ice0);
-      if (steep) {
-        const double flux_term2 = C * (TL - 2. * T + TU) - D * (TL - TU);
-        if ((T < TL && T < TU) && (flux_term1 < 0 && flux_term2 > 0) && fabs(flux_term1) > fabs(flux_term2))
-          value = -A * (T - T0) + C * (TL - 2. * T + TU) - D * (TL - TU) + E * (ice - ice0);
-      }
-    }
-    return value;
-  }
-};
-
 // ------------------------------------------------------------------------------------------------
 // Finite-difference soil temperature profile: what the ground-surface balance hands to the profile-solve kernel
-// (vic_profile.hpp).  One record per node, PREC doubles, records of one HRU contiguous ("item block"):
-//   [0] T0 (previous-step temperature; node 0: replaced by the trial surface temperature at solve time)
-//   [1] A  [2] B  [3] C  [4] D     explicit-scheme coefficients (frozen_soil.c:161-213); node 0 [1]: frozen_on flag
-//   [5] E*(0-ice)                  latent term of the closed-form (unfrozen) update
-//   [6] E  [7] moist  [8] ice      inputs of the frozen-node residual (soil_thermal_eqn.c)
-//   [9] max_moist [10] bubble [11] expt   freezing-curve parameters the reference would read for this node: the node
-//                                  arrays ("fixed"), or the LAYER arrays indexed by node as shipped ("compat",
-//                                  frozen_soil.c:218-221: max_moist in mm for j < 3, then the node arrays shifted by 3)
+// (vic_profile.hpp).  One record per node, PREC doubles, records of one HRU contiguous ("item block").
+//
+// The explicit scheme (frozen_soil.c:161-213, 380-468) updates node j from its neighbours TL = T[j+1], TU = T[j-1]:
+//   unfrozen node:  T = N / S                                  with N = A*T0 + B*(TL-TU) + C*TL + D*TU + E*(0-ice0), S = A+C+D
+//   frozen node:    root of  -A(T-T0) + B(TL-TU) + C(TL-T) - D(T-TU) + E(ice(T)-ice0)  (soil_thermal_eqn.c:47-131)
+//                   which is, term by term,  N - S*T + E*ice(T)   with the SAME N and S,
+//   ice(T) = clip(moist - u(T)), u(T) = max_moist * (-Lf*T/273.16/(g*bubble/100))^(-2/(expt-3)) clipped to max_moist
+//   (maximum_unfrozen_water, soil_conduction.c:830-863); EXP_TRANS: N and S of frozen_soil.c:194-212 instead.
+// So a record holds what both forms need, with everything that is constant over the Brent solve on Tsurf folded once
+// per sub-step here instead of once per node visit there:
+//   [0] T0     previous-step temperature (node 0: replaced by the trial surface temperature at solve time)
+//   [1] A*T0   (node 0: frozen_on flag)
+//   [2] B  [3] C  [4] D  [5] E*(0-ice0)  [6] S = A+C+D  (EXP_TRANS: A+2C)        -> N and the closed-form update keep the
+//                                                                                  reference's operation order exactly
+//   [7] G = E*max_moist*kappa^Y, kappa = Lf/273.16/(g*bubble/100)   [8] Y = -2/(expt-3)       -> E*u(T) = G*(-T)^Y
+//   [9] E*moist  [10] E*max_moist                                                               (clip levels of E*u, E*ice)
+// max_moist/bubble/expt are the node arrays ("fixed") or the LAYER arrays indexed by node as shipped ("compat",
+// frozen_soil.c:218-221: max_moist in mm for j < 3, then the node arrays shifted by 3).
 // A-D depend only on kappa, Cs, the node geometry and dt, i.e. they are the same for every residual evaluation of one
 // Brent solve on Tsurf (upstream keeps them in static arrays for that reason; SURVEY.md Finding 1.1).
 // ------------------------------------------------------------------------------------------------
-#ifndef PROFILE_RECORD_DOUBLES
-#define PROFILE_RECORD_DOUBLES 12
-#endif
-constexpr int PREC = PROFILE_RECORD_DOUBLES;     // 12 used
-enum { PR_T0 = 0, PR_A, PR_B, PR_C, PR_D, PR_EI, PR_E, PR_MOIST, PR_ICE, PR_MAXM, PR_CURVE_DIV, PR_CURVE_EXP };
+constexpr int PREC = 11;
+enum { PR_T0 = 0, PR_AT0, PR_B, PR_C, PR_D, PR_EI, PR_S, PR_G, PR_Y, PR_EMOIST, PR_EMM };
 
 template <int NN>
 VIC_DEV void profile_item_store(const Opt& o, const CellView& cv, const Soil3& s3, const Nodes<NN>& nd, double deltat, bool frozen_on,
@@ -109,33 +51,40 @@ VIC_DEV void profile_item_store(const Opt& o, const CellView& cv, const Soil3& s
     if (j >= Nn) continue;
     double* r = blk + j * PREC;
     r[PR_T0] = nd.T[j];
-    if (j == 0) { r[PR_A] = frozen_on ? 1.0 : 0.0; continue; }
+    if (j == 0) { r[PR_AT0] = frozen_on ? 1.0 : 0.0; continue; }
     if (!(j < Nn - 1 || o.NOFLUX)) continue;
     const double kup = (j < Nn - 1) ? nd.kappa[(j + 1 < NN) ? j + 1 : j] : nd.kappa[j];
-    double E;
+    double A, C, D, E;
     if (!o.EXP_TRANS) {
       const double al = cv.node(CPN_ALPHA, j - 1), be = cv.node(CPN_BETA, j - 1), ga = cv.node(CPN_GAMMA, j - 1);
-      r[PR_A] = nd.Cs[j] * al * al;
-      r[PR_B] = (kup - nd.kappa[j - 1]) * deltat;
-      r[PR_C] = 2 * deltat * nd.kappa[j] * al / ga;
-      r[PR_D] = 2 * deltat * nd.kappa[j] * al / be;
+      A = nd.Cs[j] * al * al;
+      C = 2 * deltat * nd.kappa[j] * al / ga;
+      D = 2 * deltat * nd.kappa[j] * al / be;
       E = ICE_DENSITY * LF * al * al;
+      r[PR_S] = A + C + D;
     } else {
       const double z1 = cv.node(CPN_ZSUM, j) + 1;
-      r[PR_A] = 4 * Bexp * Bexp * nd.Cs[j] * z1 * z1;
-      r[PR_B] = (kup - nd.kappa[j - 1]) * deltat;
-      r[PR_C] = 4 * deltat * nd.kappa[j];
-      r[PR_D] = 2 * deltat * nd.kappa[j] * Bexp;
+      A = 4 * Bexp * Bexp * nd.Cs[j] * z1 * z1;
+      C = 4 * deltat * nd.kappa[j];
+      D = 2 * deltat * nd.kappa[j] * Bexp;
       E = 4 * Bexp * Bexp * ICE_DENSITY * LF * z1 * z1;
+      r[PR_S] = A + 2. * C;
     }
+    r[PR_AT0] = A * nd.T[j];
+    r[PR_B] = (kup - nd.kappa[j - 1]) * deltat;
+    r[PR_C] = C; r[PR_D] = D;
     r[PR_EI] = E * (0. - nd.ice[j]);
-    r[PR_E] = E; r[PR_MOIST] = nd.moist[j]; r[PR_ICE] = nd.ice[j];
-    double bub, ex;
+    double mm, bub, ex;
     if (o.frozen_compat) {
-      if (j < 3) { r[PR_MAXM] = s3.max_moist[j]; bub = cv.lay(CPL_BUBBLE, j); ex = cv.lay(CPL_EXPT, j); }
-      else { r[PR_MAXM] = cv.node(CPN_MAX_MOIST, j - 3); bub = cv.node(CPN_BUBBLE, j - 3); ex = cv.node(CPN_EXPT, j - 3); }
-    } else { r[PR_MAXM] = cv.node(CPN_MAX_MOIST, j); bub = cv.node(CPN_BUBBLE, j); ex = cv.node(CPN_EXPT, j); }
-    r[PR_CURVE_DIV] = SoilThermalEqn::curve_divisor(bub); r[PR_CURVE_EXP] = SoilThermalEqn::curve_exponent(ex);
+      if (j < 3) { mm = s3.max_moist[j]; bub = cv.lay(CPL_BUBBLE, j); ex = cv.lay(CPL_EXPT, j); }
+      else { mm = cv.node(CPN_MAX_MOIST, j - 3); bub = cv.node(CPN_BUBBLE, j - 3); ex = cv.node(CPN_EXPT, j - 3); }
+    } else { mm = cv.node(CPN_MAX_MOIST, j); bub = cv.node(CPN_BUBBLE, j); ex = cv.node(CPN_EXPT, j); }
+    const double Y = -(2.0 / (ex - 3.0));
+    const double kap = LF / 273.16 / (9.81 * bub / 100.);
+    r[PR_Y] = Y;
+    r[PR_G] = frozen_on ? E * mm * pow_pos(kap, Y) : 0.0;
+    r[PR_EMOIST] = E * nd.moist[j];
+    r[PR_EMM] = E * mm;
   }
 }
 

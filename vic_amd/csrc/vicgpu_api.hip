@@ -5,7 +5,7 @@
 //                      prepare_full_energy, surface_fluxes (snow, ground energy balance, pot. evap), runoff.
 //                      HBM-side it is a streaming read-modify-write of the SoA state table; all physics is fp64 VALU.
 //   vic_fd_stage<NN>,  the same step for the finite-difference soil profile (FROZEN_SOIL / QUICK_FLUX off), cut at the
-//   vic_profile_solve<NN>, ground-surface root finder into a pipeline: stage kernel (everything around the root finder,
+//   vic_profile_solve_*,   ground-surface root finder into a pipeline: stage kernel (everything around the root finder,
 //   vic_surf_eval      context parked in HBM) -> rounds of { profile solves on a compacted work list ; residual +
 //                      Brent step on Tsurf } -> stage kernel.  See vic_profile.hpp for why.
 //   vic_cell_reduce    one lane per cell: atmos->out_prec/out_rain/out_snow (full_energy.c:429-431) summed in hruList
@@ -931,7 +931,7 @@ struct vicgpu_ctx {
   double *d_pin = nullptr, *d_ts = nullptr, *d_pout = nullptr;
   int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr;
   int profile_waves = 0;           // resident waves of the profile kernel
-  bool profile_lockstep = true;    // which of the two profile kernels (VICGPU_PROFILE_KERNEL=flat|lockstep)
+  bool node_newton = false;        // frozen-node root finder: safeguarded Newton instead of the reference's Brent iteration
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
 };
@@ -977,21 +977,31 @@ static hipError_t launch_fd_stage(const KArgs& ka, bool multi, hipStream_t st) {
   return hipGetLastError();
 }
 
+// The profile kernel of a node count: 10 nodes have the register-resident instantiation, every other count the generic one
 template <int NN>
-static hipError_t launch_profile(const PArgs& pa, int nmax, int resident_waves, bool lockstep, hipStream_t st) {
+static hipError_t launch_profile(const PArgs& pa, int nmax, int resident_waves, bool newton, hipStream_t st) {
   int nblk = (nmax + 63) / 64;
   if (nblk > resident_waves) nblk = resident_waves;      // persistent waves pull from the work list
   if (nblk < 1) nblk = 1;                                // block 0 also clears the counters of the round
-  if (lockstep) hipLaunchKernelGGL((vic_profile_solve_lockstep<NN>), dim3(nblk), dim3(64), 0, st, pa);
-  else hipLaunchKernelGGL((vic_profile_solve<NN>), dim3(nblk), dim3(64), 0, st, pa);
+  const dim3 g(nblk), b(64);
+  if constexpr (NN == 10) {
+    if (newton) hipLaunchKernelGGL((vic_profile_solve_reg<NN, true>), g, b, 0, st, pa);
+    else hipLaunchKernelGGL((vic_profile_solve_reg<NN, false>), g, b, 0, st, pa);
+  } else {
+    if (newton) hipLaunchKernelGGL((vic_profile_solve_lockstep<NN, true>), g, b, 0, st, pa);
+    else hipLaunchKernelGGL((vic_profile_solve_lockstep<NN, false>), g, b, 0, st, pa);
+  }
   return hipGetLastError();
 }
 
 template <int NN>
-static int profile_resident_waves(int device, bool lockstep) {
+static int profile_resident_waves(int device, bool newton) {
   int per_cu = 0, ncu = 0;
-  hipError_t e = lockstep ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve_lockstep<NN>, 64, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve<NN>, 64, 0);
+  hipError_t e;
+  if constexpr (NN == 10) e = newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve_reg<NN, true>, 64, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve_reg<NN, false>, 64, 0);
+  else e = newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve_lockstep<NN, true>, 64, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_profile_solve_lockstep<NN, false>, 64, 0);
   if (e != hipSuccess || per_cu <= 0) per_cu = 8;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
   return per_cu * ncu;
@@ -1047,8 +1057,8 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
     for (int round = 0;; round++) {
       pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur * NBUCKET; pa.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
       pa.evalonly_zero = ch->d_count + CNT_EVALONLY;
-      CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, c->profile_lockstep, st)
-                     : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, c->profile_lockstep, st)));
+      CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, c->node_newton, st)
+                     : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, c->node_newton, st)));
       ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1) * NBUCKET;
       hipLaunchKernelGGL(vic_surf_eval, dim3((ch->gcount + 63) / 64), dim3(64), 0, st, ea);
       CHKCH(ch, hipGetLastError());
@@ -1160,6 +1170,7 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   if (opt->FROZEN_SOIL && opt->QUICK_FLUX) return VICGPU_ERR_ARG;            // get_global_param.c:376-381
   // options of the reference this library does not implement are refused, never silently replaced
   if (opt->BLOWING || opt->QUICK_SOLVE || opt->IMPLICIT) return VICGPU_ERR_UNSUPPORTED;
+  if (opt->NODE_SOLVER != VIC_NODE_SOLVER_BRENT && opt->NODE_SOLVER != VIC_NODE_SOLVER_NEWTON) return VICGPU_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VICGPU_ERR_HIP;   // no CPU fallback: fail loudly
   if (device < 0 || device >= ndev) return VICGPU_ERR_ARG;
@@ -1296,11 +1307,11 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
     HIPCHK(c, hipMemset(c->d_hstate, 0, sizeof(int) * nhru));
     HIPCHK(c, hipMemset(c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, hipMemset(c->d_pout, 0, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
-    // the profile kernel: lock-step over the keyed work lists by default, the flat per-lane state machine on request
-    c->profile_lockstep = true;
-    if (const char* ev = getenv("VICGPU_PROFILE_KERNEL")) c->profile_lockstep = (strcmp(ev, "flat") != 0);
-    c->profile_waves = (Nn == 10) ? profile_resident_waves<10>(c->device, c->profile_lockstep)
-                                  : profile_resident_waves<VIC_MAX_NODES>(c->device, c->profile_lockstep);
+    // frozen-node root finder (vic_profile.hpp): the option, overridable for A/B runs
+    c->node_newton = c->opt.NODE_SOLVER == VIC_NODE_SOLVER_NEWTON;
+    if (const char* ev = getenv("VICGPU_NODE_SOLVER")) c->node_newton = (strcmp(ev, "newton") == 0);
+    c->profile_waves = (Nn == 10) ? profile_resident_waves<10>(c->device, c->node_newton)
+                                  : profile_resident_waves<VIC_MAX_NODES>(c->device, c->node_newton);
     // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  One chunk is the
     // default: the persistent profile kernel fills every SIMD, so concurrent chunks mostly queue behind each other.
     int nchunk = 1;
