@@ -166,6 +166,10 @@ typedef struct {
   int NF, NR;
   int nveg_rows;
   const double *veglib;   /* [nveg_rows][VL_NFIELD] */
+  /* stopping tolerance 2*macheps*|b| + ttol of the frozen-NODE root finds only (root_brent.c:32-36,274: 3e-8, 1e-7).
+   * A test-only knob (vicorc_set_node_tolerance): tightened, the restatement converges those roots fully, which separates
+   * the reference's own stopping error from implementation error when the product's Newton node solver is checked. */
+  double node_macheps, node_ttol;
 } orc_model;
 
 static inline const double *orc_veg(const orc_model *m, int idx) { return m->veglib + (size_t)idx * VL_NFIELD; }
@@ -178,6 +182,7 @@ double orc_penman(double tair, double elevation, double rad, double vpd, double 
 double orc_stability_correction(double Z, double d, double TSurf, double Tair, double Wind, double Z0);
 typedef double (*orc_fn)(double x, void *ctx);
 double orc_root_brent(double lower, double upper, orc_fn f, void *ctx);
+double orc_root_brent_tol(double lower, double upper, orc_fn f, void *ctx, double MACHEPS, double TTOL);
 double orc_calc_veg_height(double displacement, double L);
 int    orc_calc_aerodynamic(int overstory, double height, double trunk, double z0_snow, double z0_soil, double n,
                             orc_vc *aero_resist, orc_vc *wind_speed, orc_vc *displacement, orc_vc *ref_height, orc_vc *roughness);

@@ -74,8 +74,12 @@ double orc_stability_correction(double Z, double d, double TSurf, double Tair, d
 
 /* ------------------------------------------------------------------ root_brent.c:97-337 */
 double orc_root_brent(double lower, double upper, orc_fn f, void *ctx) {
+  return orc_root_brent_tol(lower, upper, f, ctx, 3e-8, 1e-7);                      /* root_brent.c:32-36 */
+}
+
+double orc_root_brent_tol(double lower, double upper, orc_fn f, void *ctx, double MACHEPS, double TTOL) {
   const int MAXTRIES = 5, MAXITER = 1000;
-  const double MACHEPS = 3e-8, TSTEP = 10, TTOL = 1e-7;
+  const double TSTEP = 10;
   double a = lower, b = upper, c = 0, d = 0, e = 0, fa, fb, fc, m, p, q, r, s, tol;
   double last_bad = 0, last_good = 0;
   int which_err = 0, i, j;

@@ -426,6 +426,7 @@ void *vicorc_create(const vicgpu_options *opt) {
   h->model.opt = *opt;
   h->model.NF = VICGPU_NF(opt);
   h->model.NR = VICGPU_NR(opt);
+  h->model.node_macheps = 3e-8; h->model.node_ttol = 1e-7;                        /* root_brent.c:32-36 */
   return h;
 }
 
@@ -753,6 +754,14 @@ int vicorc_pure(void *hv, int fn, int n, const double *in, double *out) {
     }
     out[i] = r;
   }
+  return 0;
+}
+
+/* test-only: stopping tolerance of the frozen-node root finds (orc.h) */
+int vicorc_set_node_tolerance(void *hv, double macheps, double ttol) {
+  vicorc_handle *h = (vicorc_handle *)hv;
+  if (!h || !(macheps >= 0) || !(ttol > 0)) return -1;
+  h->model.node_macheps = macheps; h->model.node_ttol = ttol;
   return 0;
 }
 

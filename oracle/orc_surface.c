@@ -120,7 +120,10 @@ static int orc_solve_T_profile(const orc_model *m, double *T, const double *T0, 
         c.TL = T[j + 1]; c.TU = T[j - 1]; c.T0 = T0[j]; c.moist = moist[j];
         orc_node_freeze_params(m, sc, j, &c.max_moist, &c.bubble, &c.expt);
         c.ice0 = ice[j]; c.A = A[j]; c.B = B[j]; c.C = C[j]; c.D = D[j]; c.E = E[j]; c.EXP_TRANS = EXP_TRANS; c.node = j;
-        T[j] = orc_root_brent(T0[j] - (ORC_SOIL_DT), T0[j] + (ORC_SOIL_DT), orc_soil_thermal_eqn, &c);
+        /* the cold-nose variant of the residual (node 1, |TL - TU| > 5) is discontinuous: its root depends on the
+         * iteration's path, so the test knob (orc.h) never applies to it */
+        if (j == 1 && fabs(c.TL - c.TU) > 5.) T[j] = orc_root_brent(T0[j] - (ORC_SOIL_DT), T0[j] + (ORC_SOIL_DT), orc_soil_thermal_eqn, &c);
+        else T[j] = orc_root_brent_tol(T0[j] - (ORC_SOIL_DT), T0[j] + (ORC_SOIL_DT), orc_soil_thermal_eqn, &c, m->node_macheps, m->node_ttol);
         if (orc_is_error(T[j])) {
           if (m->opt.TFALLBACK) { T[j] = T0[j]; Tfbflag[j] = 1; Tfbcount[j]++; }
           else return -1;
@@ -144,7 +147,7 @@ static int orc_solve_T_profile(const orc_model *m, double *T, const double *T0, 
         c.TL = T[j]; c.TU = T[j - 1]; c.T0 = T0[j]; c.moist = moist[j];
         orc_node_freeze_params(m, sc, j, &c.max_moist, &c.bubble, &c.expt);
         c.ice0 = ice[j]; c.A = A[j]; c.B = B[j]; c.C = C[j]; c.D = D[j]; c.E = E[j]; c.EXP_TRANS = EXP_TRANS; c.node = j;
-        T[j] = orc_root_brent(T0[j] - ORC_SOIL_DT, T0[j] + ORC_SOIL_DT, orc_soil_thermal_eqn, &c);
+        T[j] = orc_root_brent_tol(T0[j] - ORC_SOIL_DT, T0[j] + ORC_SOIL_DT, orc_soil_thermal_eqn, &c, m->node_macheps, m->node_ttol);
         if (orc_is_error(T[j])) {
           if (m->opt.TFALLBACK) { T[j] = T0[j]; Tfbflag[j] = 1; Tfbcount[j]++; }
           else return -1;

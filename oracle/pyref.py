@@ -154,9 +154,15 @@ class RefModel(_Model):
 class OracleModel(_Model):
     prefix = "vicorc_"
 
-    def __init__(self, dom):
+    def __init__(self, dom, converged_nodes=False):
+        """converged_nodes: the frozen-node root finds (soil_thermal_eqn.c) iterate to 1e-13 K instead of the reference's
+        1e-7 K -- the checker for the product's Newton node solver, which converges those roots fully (orc.h)."""
         lib = ctypes.CDLL(oracle_lib_path())
         super().__init__(lib, dom)
+        if converged_nodes:
+            lib.vicorc_set_node_tolerance.restype = ctypes.c_int
+            lib.vicorc_set_node_tolerance.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
+            assert lib.vicorc_set_node_tolerance(self.h, 1e-16, 1e-13) == 0
 
 
 def have_ref(variant="plain"):

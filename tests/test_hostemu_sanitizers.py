@@ -46,12 +46,13 @@ def test_monolithic_kernel_clean(hostemu_lib, poison):
 
 @pytest.mark.parametrize("poison", [False, True])
 def test_fd_pipeline_clean(hostemu_lib, poison):
-    """vic_fd_stage -> { vic_profile_solve_lockstep ; vic_surf_eval } rounds -> vic_fd_stage, work lists included."""
+    """vic_fd_stage -> { vic_profile_solve_reg ; vic_surf_eval } rounds -> vic_fd_stage, work lists included."""
     out = _run(*hostemu_lib, ["3", "2", "frozen_fixed", "frozen_compat", "glacier_frozen"], poison)
     assert out.count("worst rel diff") == 3
 
 
-def test_fd_pipeline_flat_kernel_clean(hostemu_lib):
-    """The per-lane-mode profile kernel (VICGPU_PROFILE_KERNEL=flat) and the sub-stepped water-balance case."""
-    out = _run(*hostemu_lib, ["3", "2", "frozen_fixed", "frozen_wb_daily"], False, VICGPU_PROFILE_KERNEL="flat")
-    assert out.count("worst rel diff") == 2
+def test_fd_pipeline_newton_and_generic_kernel_clean(hostemu_lib):
+    """The Newton node solver (VICGPU_NODE_SOLVER=newton) in the register-resident 10-node kernel and in the generic one
+    (8 nodes), and the sub-stepped water-balance case."""
+    out = _run(*hostemu_lib, ["3", "2", "frozen_fixed", "frozen_wb_daily", "frozen_fixed_n8"], False, VICGPU_NODE_SOLVER="newton")
+    assert out.count("worst rel diff") == 3

@@ -18,7 +18,8 @@ def main():
     for name in sys.argv[3:]:
         kw, _, ntile, doy = tg.CASES[name]
         d, f, sf, dmy, sd0, si0 = tg._setup(kw, ncell, ntile, nsteps, doy)
-        orc = pyref.OracleModel(d); orc.set_state(sd0, si0)
+        # VICGPU_NODE_SOLVER=newton: the Newton node solver against the oracle with converged node roots (tests/test_gpu_parity.py)
+        orc = pyref.OracleModel(d, converged_nodes=os.environ.get("VICGPU_NODE_SOLVER") == "newton"); orc.set_state(sd0, si0)
         dev = Model(d); dev.push_forcing(f, sf, dmy)
         w_all = 0.0
         for s in range(nsteps):
