@@ -203,7 +203,7 @@ def test_teacher_forced_option_branches(name, solver, oracle_lib):
 
 # rows north_star names as the outputs to match: runoff, baseflow, SWE, soil moisture, glacier mass balance
 HEADLINE_STATE_ROWS = [C[k] for k in ("SD_MOIST0", "SD_MOIST1", "SD_MOIST2", "SD_SNOW_SWQ", "SD_GLAC_CUM_MASS_BALANCE", "SD_GLAC_WATER_STORAGE")]
-HEADLINE_FLUX_ROWS = [C[k] for k in ("FX_RUNOFF", "FX_BASEFLOW", "FX_EVAP0", "FX_EVAP1", "FX_EVAP2", "FX_CANOPYEVAP", "FX_SNOW_MELT")]
+HEADLINE_FLUX_ROWS = [C[k] for k in ("FX_RUNOFF", "FX_BASEFLOW", "FX_SNOW_MELT", "FX_CANOPYEVAP")]
 
 
 def _golden_solver_cases():
