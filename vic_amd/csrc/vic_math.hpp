@@ -404,6 +404,45 @@ VIC_DEV double soil_conductivity(double moist, double Wu, double soil_dens_min, 
   return K;
 }
 
+// The same with the layer's constants taken from the derived rows of the cell table: Kdry, Ks^(1-porosity),
+// Kw^porosity and the porosity are computed once per domain by soil_conductivity_layer_constants with the expressions
+// and the pow of soil_conductivity itself, so the result is identical; three of the five pow calls and the quartz branch
+// leave the per-node, per-step path.
+struct SoilKLayer { double Kdry, KsP, KwP, porosity; };
+VIC_DEV SoilKLayer soil_conductivity_layer_constants(double soil_dens_min, double bulk_dens_min, double quartz, double soil_density,
+                                                     double bulk_density, double organic) {
+  const double Kw = 0.57, Kdry_org = 0.05, Ks_org = 0.25;
+  SoilKLayer c;
+  double Kdry_min = (0.135 * bulk_dens_min + 64.7) / (soil_dens_min - 0.947 * bulk_dens_min);
+  c.Kdry = (1 - organic) * Kdry_min + organic * Kdry_org;
+  c.porosity = 1.0 - bulk_density / soil_density;
+  double Ks_min;
+  if (quartz < .2) Ks_min = pow(7.7, quartz) * pow(3.0, 1.0 - quartz);
+  else Ks_min = pow(7.7, quartz) * pow(2.2, 1.0 - quartz);
+  const double Ks = (1 - organic) * Ks_min + organic * Ks_org;
+  c.KsP = pow(Ks, 1.0 - c.porosity);
+  c.KwP = pow(Kw, c.porosity);
+  return c;
+}
+VIC_DEV double soil_conductivity_pre(double moist, double Wu, const SoilKLayer& c) {
+  const double Ki = 2.2, Kw = 0.57;
+  double K;
+  if (moist > 0.) {
+    double Sr = moist / c.porosity;
+    double Ksat, Ke;
+    if (Wu == moist) {
+      Ksat = c.KsP * c.KwP;
+      Ke = 0.7 * log10(Sr) + 1.0;
+    } else {
+      Ksat = c.KsP * pow(Ki, c.porosity - Wu) * pow(Kw, Wu);
+      Ke = Sr;
+    }
+    K = (Ksat - c.Kdry) * Ke + c.Kdry;
+    if (K < c.Kdry) K = c.Kdry;
+  } else K = c.Kdry;
+  return K;
+}
+
 // soil_conduction.c:108-139
 VIC_DEV double volumetric_heat_capacity(double soil_fract, double water_fract, double ice_fract, double organic_fract) {
   double Cs = 2.0e6 * soil_fract * (1 - organic_fract);

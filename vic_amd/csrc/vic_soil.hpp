@@ -13,7 +13,8 @@ VIC_DEV void top_layer_thermal_properties(const CellView& cv, const Soil3& s3, c
     double m = moist[l] / s3.depth[l] / 1000;
     double ic = ice[l] / s3.depth[l] / 1000;
     double bd = cv.lay(CPL_BULK_DENSITY, l), sd = cv.lay(CPL_SOIL_DENSITY, l), org = cv.lay(CPL_ORGANIC, l);
-    kappa2[l] = soil_conductivity(m, m - ic, cv.lay(CPL_SOIL_DENS_MIN, l), cv.lay(CPL_BULK_DENS_MIN, l), cv.lay(CPL_QUARTZ, l), sd, bd, org);
+    const SoilKLayer kc{cv.x(CPX_KDRY, l), cv.x(CPX_KSP, l), cv.x(CPX_KWP, l), cv.x(CPX_POROSITY, l)};
+    kappa2[l] = soil_conductivity_pre(m, m - ic, kc);
     Cs2[l] = volumetric_heat_capacity(bd / sd, m - ic, ic, org);
   }
 }
@@ -27,6 +28,13 @@ VIC_DEV void distribute_node_moisture_properties(const Opt& o, const CellView& c
   bool past_bottom = false;
   double Lsum = 0.;
   const bool fs = (cv.s(CP_FS_ACTIVE) != 0.0) && o.FROZEN_SOIL;
+  // per-layer constants of the loop body, selected by the run-time layer index below
+  double lbd[3], lsd[3], lorg[3], lKdry[3], lKsP[3], lKwP[3], lpor[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    lbd[q] = cv.lay(CPL_BULK_DENSITY, q); lsd[q] = cv.lay(CPL_SOIL_DENSITY, q); lorg[q] = cv.lay(CPL_ORGANIC, q);
+    lKdry[q] = cv.x(CPX_KDRY, q); lKsP[q] = cv.x(CPX_KSP, q); lKwP[q] = cv.x(CPX_KWP, q); lpor[q] = cv.x(CPX_POROSITY, q);
+  }
 #pragma unroll
   for (int n = 0; n < NN; n++) {
     if (n < Nn) {
@@ -36,15 +44,15 @@ VIC_DEV void distribute_node_moisture_properties(const Opt& o, const CellView& c
       if (z == Lsum + dl && n != 0 && l != 2) nd.moist[n] = (sel3(moist, l) / dl + sel3(moist, l + 1) / sel3(s3.depth, l + 1)) / 1000 / 2.;
       else nd.moist[n] = sel3(moist, l) / dl / 1000;
       if (nd.moist[n] - mmn > 0) nd.moist[n] = mmn;
-      double bd = cv.lay(CPL_BULK_DENSITY, l), sd = cv.lay(CPL_SOIL_DENSITY, l), org = cv.lay(CPL_ORGANIC, l);
-      double sdm = cv.lay(CPL_SOIL_DENS_MIN, l), bdm = cv.lay(CPL_BULK_DENS_MIN, l), qz = cv.lay(CPL_QUARTZ, l);
+      const double bd = sel3(lbd, l), sd = sel3(lsd, l), org = sel3(lorg, l);
+      const SoilKLayer kc{sel3(lKdry, l), sel3(lKsP, l), sel3(lKwP, l), sel3(lpor, l)};
       if (nd.T[n] < 0 && fs) {
         nd.ice[n] = nd.moist[n] - maximum_unfrozen_water(nd.T[n], mmn, cv.node(CPN_BUBBLE, n), cv.node(CPN_EXPT, n));
         if (nd.ice[n] < 0) nd.ice[n] = 0;
-        nd.kappa[n] = soil_conductivity(nd.moist[n], nd.moist[n] - nd.ice[n], sdm, bdm, qz, sd, bd, org);
+        nd.kappa[n] = soil_conductivity_pre(nd.moist[n], nd.moist[n] - nd.ice[n], kc);
       } else {
         nd.ice[n] = 0;
-        nd.kappa[n] = soil_conductivity(nd.moist[n], nd.moist[n], sdm, bdm, qz, sd, bd, org);
+        nd.kappa[n] = soil_conductivity_pre(nd.moist[n], nd.moist[n], kc);
       }
       nd.Cs[n] = volumetric_heat_capacity(bd / sd, nd.moist[n] - nd.ice[n], nd.ice[n], org);
       if (z > Lsum + dl && !past_bottom) {

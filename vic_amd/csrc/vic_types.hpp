@@ -106,10 +106,17 @@ struct VegLib {
   VIC_DEV double f(int idx, int field) const { return t[idx * VL_NFIELD + field]; }
 };
 
+// Rows the library appends to its device copy of the cell parameter table (vic_derive_cell_params, once per
+// vicgpu_set_domain): the factors of soil_conductivity (soil_conduction.c:7-105) that depend on the layer's soil only.
+enum { CPX_KDRY = 0, CPX_KSP, CPX_KWP, CPX_POROSITY, CPX_NFIELD };
+#define VIC_CPX_ROW(f, l, Nn, Nb) (VICGPU_CP_NROW(Nn, Nb) + (f) * VIC_NLAYER + (l))
+#define VIC_CPX_NROW(Nn, Nb) (VICGPU_CP_NROW(Nn, Nb) + CPX_NFIELD * VIC_NLAYER)
+
 struct CellView {
-  const double* __restrict__ cp;   // [CP_NROW][ncell]
+  const double* __restrict__ cp;   // [CP_NROW + derived rows][ncell]
   int ncell, c, Nn, Nb;
   VIC_DEV double s(int row) const { return cp[(size_t)row * ncell + c]; }
+  VIC_DEV double x(int f, int l) const { return s(VIC_CPX_ROW(f, l, Nn, Nb)); }
   VIC_DEV double lay(int f, int l) const { return s(VICGPU_CP_LAYER(f, l)); }
   VIC_DEV double node(int f, int n) const { return s(VICGPU_CP_NODE(f, n, Nn)); }
   VIC_DEV double band(int f, int b) const { return s(VICGPU_CP_BAND(f, b, Nn, Nb)); }

@@ -66,7 +66,6 @@ struct KArgs {
   int list_cap;
   int* hkey;                        // [nhru] work-list segment of each HRU (number of frozen nodes)
   int phase;                        // 0: start of the step; p >= 1: after the root finder of sub-step p - 1
-  int* cursor;                      // work-list cursor of the solve kernel that follows (cleared here), or null
 };
 
 // ------------------------------------------------------------------------------------------------ parked context
@@ -532,7 +531,6 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
 template <int NN, bool FIRST, bool MULTI>
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const KArgs a) {
   const int gi = blockIdx.x * 64 + threadIdx.x;
-  if (gi == 0 && a.cursor) *a.cursor = 0;
   if (gi >= a.gcount) return;
   const int g = a.glist ? a.glist[gi] : gi;
   const Opt& o = a.o;
@@ -695,18 +693,24 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
   const double* __restrict__ rec = a.pout + (size_t)g * pout_hru_stride(a.Nn);
   // the record the profile kernel has just written, or the one found on record for the final evaluation
-  const int slot = sv.on_record ? sv.final_slot : a.pslot[g];
-  const double* __restrict__ po = rec + slot * pout_stride(a.Nn);
-  const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
-  if (sv.stage == SurfSolve::FINAL) sv.final_slot = slot;
-  const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
-  surf_solve_consume(a.o, sv, eb, fx);
-  bool need_solve = sv.stage != SurfSolve::DONE;
-  if (sv.stage == SurfSolve::FINAL) {
-    // the root has been found: the final evaluation needs the profile at sv.x, which is on record if sv.x is one of the
-    // last two trial points; the evaluation itself happens in the next round, together with everybody else's
-    if (rec[pout_key(a.Nn, slot)] == sv.x) { sv.final_slot = slot; sv.on_record = 1; need_solve = false; }
-    else if (rec[pout_key(a.Nn, slot ^ 1)] == sv.x) { sv.final_slot = slot ^ 1; sv.on_record = 1; need_solve = false; }
+  int slot = sv.on_record ? sv.final_slot : a.pslot[g];
+  bool need_solve = false;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const double* __restrict__ po = rec + slot * pout_stride(a.Nn);
+    const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
+    if (sv.stage == SurfSolve::FINAL) sv.final_slot = slot;
+    const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
+    surf_solve_consume(a.o, sv, eb, fx);
+    need_solve = sv.stage != SurfSolve::DONE;
+    if (sv.stage != SurfSolve::FINAL) break;
+    // The root has been found: the final evaluation needs the profile at sv.x, which is on record if sv.x is one of the
+    // last two trial points (the same inputs give the same profile bit for bit).  Then the final evaluation is made right
+    // here, while the HRU's context is in registers, instead of in a round of its own.
+    if (rec[pout_key(a.Nn, slot)] == sv.x) sv.final_slot = slot;
+    else if (rec[pout_key(a.Nn, slot ^ 1)] == sv.x) { slot ^= 1; sv.final_slot = slot; }
+    else break;                                    // the solver fell back to a temperature it never evaluated: one more solve
+    sv.on_record = 1;
   }
   ctx_put(cx, CO_SV, sv);
   ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, (int)CW_EBM_FEED);
@@ -718,303 +722,6 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
     const unsigned long long m = __ballot(sv.stage != SurfSolve::DONE && !need_solve);
     if (m != 0 && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(a.evalonly, __popcll(m));
   }
-}
-
-// ------------------------------------------------------------------------------------------------ fused Tsurf solve
-// The whole Brent iteration on the ground-surface temperature of one sub-step (calc_surf_energy_bal.c:346-511) in ONE
-// persistent kernel: lane = one HRU from the bracket evaluations to the final evaluation at the root.  Per trial
-// temperature the wave solves the soil temperature profiles of its 64 HRUs in lock step (vic_profile.hpp: node_visit,
-// Gauss-Seidel sweeps with a per-lane sweep count), then every lane evaluates the rest of its residual (SurfEB::eval) and
-// takes one step of ITS Brent iteration; a lane whose iteration is through writes its results back and takes the next HRU
-// of the keyed work list at the gate.  What an HRU needs for all of this is loaded ONCE: the node constants of the item
-// block and the node temperatures into registers, the Brent state and the evaluation's read-modify-write fields into
-// registers, the evaluation's constants (SurfEBConst, 63 words) into LDS -- 1 wave per SIMD, 4 per CU.  The profile at
-// the root is the last one solved whenever the root is the last trial point (otherwise it is solved once more: same
-// inputs, same bits).  No work lists between evaluations, no host round trip: a sub-step is stage kernel -> this kernel
-// -> stage kernel.
-struct TArgs {
-  Opt o;
-  int ncell, nhru, Nn;
-  const double* cell_params;
-  const int* hpi;
-  unsigned long long* ctx;
-  size_t ctx_words;
-  const double* pin;                 // item blocks [nhru][Nn][PREC]
-  double* pout;                      // profile of the final evaluation: record 0 of [nhru][pout_hru_stride(Nn)]
-  int* hstate;
-  const int* list;                   // HRUs to solve: NBUCKET segments of `cap` entries
-  const int* count;                  // entries per segment [NBUCKET]
-  int cap;
-  int* next;                         // work-list cursor (cleared by the stage kernel before)
-  int* count_zero;                   // segment counters of the list the following stage kernel appends to (cleared here)
-};
-
-template <int NN, bool NEWTON>
-__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_tsurf_solve(const TArgs a) {
-  constexpr bool REG = (NN <= 10);                     // node constants and temperatures in registers (node loop unrolled)
-  constexpr int NK = REG ? NN - 1 : 1;
-  __shared__ int bcount[NBUCKET];
-  __shared__ double T0l[NN * 64];
-  __shared__ double Tl[(REG ? 1 : NN) * 64];
-  __shared__ unsigned long long ebcl[CW_EBC * 64];
-  const int lane = threadIdx.x;
-#define T0(j) T0l[(j) * 64 + lane]
-#define TL(j) Tl[(j) * 64 + lane]
-  for (int b = lane; b < NBUCKET; b += 64) bcount[b] = a.count[b];
-  if (blockIdx.x == 0)
-    for (int b = lane; b < NBUCKET; b += 64) a.count_zero[b] = 0;
-  __syncthreads();
-  int n = 0;
-#pragma unroll
-  for (int b = 0; b < NBUCKET; b++) n += bcount[b];
-  if ((int)blockIdx.x * 64 >= n) return;
-
-  const int Nn = REG ? NN : a.Nn;
-  const int jlast = a.o.NOFLUX ? Nn : Nn - 1;
-  const int MAXIT = 1000;
-  const double threshold = 1.e-2;
-  const bool EXP_TRANS = a.o.EXP_TRANS != 0;
-  const bool TFALLBACK = a.o.TFALLBACK != 0;
-
-  bool have = false, more = true, frozen_on = false, ok = true;
-  int hru = 0, evcnt = 0;
-  unsigned fbmask = 0;
-  double lastTs = NAN;
-  int cadd[NN];
-  double T[REG ? NN : 1];
-  double kAT0[NK], kB[NK], kC[NK], kD[NK], kEI[NK], kS[NK], kG[NK], kY[NK], kEM[NK], kEMM[NK];
-  SurfSolve sv;
-  SurfEBMut mut;
-  Soil3 s3;
-  {
-    unsigned long long z1[sizeof(SurfSolve) / 8] = {0}, z2[sizeof(SurfEBMut) / 8] = {0}, z3[sizeof(Soil3) / 8] = {0};
-    __builtin_memcpy(&sv, z1, sizeof(sv)); __builtin_memcpy(&mut, z2, sizeof(mut)); __builtin_memcpy(&s3, z3, sizeof(s3));
-  }
-#pragma unroll
-  for (int k = 0; k < NN; k++) cadd[k] = 0;
-#pragma unroll
-  for (int k = 0; k < (REG ? NN : 1); k++) T[k] = 0;
-#pragma unroll
-  for (int k = 0; k < NK; k++) { kAT0[k] = 0; kB[k] = 0; kC[k] = 0; kD[k] = 0; kEI[k] = 0; kS[k] = 1; kG[k] = 0; kY[k] = 0; kEM[k] = 0; kEMM[k] = 0; }
-
-  while (true) {
-    // ---- gate: lanes without an HRU take the next entries of the work list
-    const unsigned long long idle = __ballot(!have);
-    if (more && (__popcll(idle) >= LOCKSTEP_GATE || idle == ~0ull)) {
-      const int nidle = __popcll(idle), leader = __ffsll((long long)idle) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(a.next, nidle);
-      base = __builtin_amdgcn_readlane(base, leader);
-      if (base + nidle >= n) more = false;
-      const int slot = base + __popcll(idle & ((1ull << lane) - 1ull));
-      if (!have && slot < n) {
-        {
-          int rem = slot, found = 0;              // segment of this slot, highest key (most frozen nodes) first
-#pragma unroll 1
-          for (int b = NBUCKET - 1; b >= 0; b--) {
-            const int cb = bcount[b];
-            if (rem < cb) { found = b * a.cap + rem; break; }
-            rem -= cb;
-          }
-          hru = a.list[found];
-        }
-        const CtxRef cx = CtxRef::at(a.ctx, a.ctx_words, hru);
-        ctx_get(cx, CO_SV, sv);
-        ctx_get_words(cx, CO_EBM, mut, 0, (int)CW_EBM_FEED);
-        {
-          const unsigned long long* __restrict__ q = cx.p + CO_EBC * 64;
-#pragma unroll
-          for (int w = 0; w < (int)CW_EBC; w++) ebcl[w * 64 + lane] = q[(size_t)w * 64];
-        }
-        const int c = a.hpi[(size_t)HPI_CELL * a.nhru + hru];
-        CellView cv{a.cell_params, a.ncell, c, a.o.Nnode, a.o.Nband};
-        s3 = load_soil3(cv);
-        const double* __restrict__ blk = a.pin + (size_t)hru * Nn * PREC;
-        frozen_on = blk[PR_AT0] != 0.0;
-#pragma unroll
-        for (int k = 1; k < NN; k++)
-          if (k < Nn) T0(k) = blk[k * PREC + PR_T0];
-        if constexpr (REG) {
-#pragma unroll
-          for (int k = 1; k < NN - 1; k++) {
-            const double* __restrict__ r = blk + k * PREC;
-            kAT0[k] = r[PR_AT0]; kB[k] = r[PR_B]; kC[k] = r[PR_C]; kD[k] = r[PR_D]; kEI[k] = r[PR_EI]; kS[k] = r[PR_S];
-            kG[k] = r[PR_G]; kY[k] = r[PR_Y]; kEM[k] = r[PR_EMOIST]; kEMM[k] = r[PR_EMM];
-          }
-        }
-        have = true;
-        lastTs = NAN;
-        sv.final_slot = 0; sv.on_record = 0;
-      }
-    }
-    if (!__any(have)) break;
-
-    // ---- the soil profile at this lane's trial temperature (func_surf_energy_bal.c:190), unless it is the one just solved
-    const bool solving = have && !(sv.stage == SurfSolve::FINAL && sv.x == lastTs);
-    bool converged = (jlast <= 1);
-    int it = 1;
-    if (solving) {
-      const double Ts = sv.x;
-      T0(0) = Ts;
-      if constexpr (REG) {
-        T[0] = Ts;
-#pragma unroll
-        for (int k = 1; k < NN; k++) T[k] = T0(k);
-      } else {
-        TL(0) = Ts;
-#pragma unroll 1
-        for (int k = 1; k < Nn; k++) TL(k) = T0(k);
-      }
-      fbmask = 0; evcnt = 0; ok = true;
-    }
-    bool sweeping = solving && !converged;
-    while (__any(sweeping)) {
-      double maxdiff = threshold;
-      PROF_WAVE(16); PROF_VOTE(17, sweeping);
-      if constexpr (REG) {
-#pragma unroll
-        for (int j = 1; j < NN; j++) {
-          if (j < jlast) {
-            const double oldT = T[j];
-            const double Tdn = (j == Nn - 1) ? oldT : T[(j + 1 < NN) ? j + 1 : j], Tup = T[j - 1];
-            const double T0j = T0(j);
-            NodeK Kj;
-            if (j == NN - 1) Kj.load(a.pin + ((size_t)hru * Nn + j) * PREC);      // the bottom node (NOFLUX only) is not cached
-            else {
-              const int jj = (j < NN - 1) ? j : 1;
-              Kj.AT0 = kAT0[jj]; Kj.B = kB[jj]; Kj.C = kC[jj]; Kj.D = kD[jj]; Kj.EI = kEI[jj]; Kj.S = kS[jj]; Kj.G = kG[jj];
-              Kj.Y = kY[jj]; Kj.EM = kEM[jj]; Kj.EMM = kEMM[jj];
-            }
-            bool failed;
-            double newT;
-            if (j == 1) newT = node_visit<true, NEWTON>(sweeping, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
-            else newT = node_visit<false, NEWTON>(sweeping, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
-            if (sweeping) {
-              if (failed) {
-                if (TFALLBACK) {
-                  // node fallback: T0 and a count, kept in the solution record (rare path): the first event of a solve clears
-                  // the counters there, the write-back adds the end-of-solve events or, without any event, writes them whole
-                  int* cnt = reinterpret_cast<int*>(a.pout + (size_t)hru * pout_hru_stride(Nn) + Nn + 1);
-                  if (evcnt == 0) {
-#pragma unroll
-                    for (int k = 0; k < NN; k++) cnt[k] = 0;
-                  }
-                  evcnt = 1;
-                  cnt[j] += 1;
-                  newT = T0j; fbmask |= (1u << j);
-                } else { ok = false; sweeping = false; }
-              }
-              if (sweeping) {
-                T[j] = newT;
-                const double diff = fabs(oldT - newT);
-                if (diff > maxdiff) maxdiff = diff;
-              }
-            }
-          }
-        }
-      } else {
-#pragma unroll 1
-        for (int j = 1; j < NN; j++) {
-          if (j < jlast) {
-            double oldT = 0, Tdn = 0, Tup = 0, T0j = 0;
-            NodeK Kj;
-            Kj.AT0 = 0; Kj.B = 0; Kj.C = 0; Kj.D = 0; Kj.EI = 0; Kj.S = 1; Kj.G = 0; Kj.Y = 0; Kj.EM = 0; Kj.EMM = 0;
-            if (sweeping) {
-              oldT = TL(j);
-              Tdn = (j == Nn - 1) ? oldT : TL((j + 1 < NN) ? j + 1 : j); Tup = TL(j - 1);
-              T0j = T0(j);
-              Kj.load(a.pin + ((size_t)hru * Nn + j) * PREC);
-            }
-            bool failed;
-            double newT;
-            if (j == 1) newT = node_visit<true, NEWTON>(sweeping, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
-            else newT = node_visit<false, NEWTON>(sweeping, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
-            if (sweeping) {
-              if (failed) {
-                if (TFALLBACK) {
-                  int* cnt = reinterpret_cast<int*>(a.pout + (size_t)hru * pout_hru_stride(Nn) + Nn + 1);
-                  if (evcnt == 0) {
-#pragma unroll 1
-                    for (int k = 0; k < Nn; k++) cnt[k] = 0;
-                  }
-                  evcnt = 1;
-                  cnt[j] += 1;
-                  newT = T0j; fbmask |= (1u << j);
-                } else { ok = false; sweeping = false; }
-              }
-              if (sweeping) {
-                TL(j) = newT;
-                const double diff = fabs(oldT - newT);
-                if (diff > maxdiff) maxdiff = diff;
-              }
-            }
-          }
-        }
-      }
-      if (sweeping) {                               // end of a Gauss-Seidel sweep (frozen_soil.c:466)
-        if (maxdiff <= threshold) { converged = true; sweeping = false; }
-        else if (it >= MAXIT) sweeping = false;
-        else it++;
-      }
-    }
-    double T1 = 0, T2 = 0;
-    if (solving) {                                  // cold-nose hack, non-convergence (frozen_soil.c:470-493)
-      double T0v[NN];
-#pragma unroll
-      for (int k = 0; k < NN; k++) T0v[k] = (k < Nn) ? T0(k) : 0.0;
-      if constexpr (REG) profile_finish<NN>(Nn, TFALLBACK, converged, ok, fbmask, T, T0v, cadd);
-      else {
-        double Tv[NN];
-#pragma unroll
-        for (int k = 0; k < NN; k++) Tv[k] = (k < Nn) ? TL(k) : 0.0;
-        profile_finish<NN>(Nn, TFALLBACK, converged, ok, fbmask, Tv, T0v, cadd);
-#pragma unroll
-        for (int k = 0; k < NN; k++)
-          if (k < Nn) TL(k) = Tv[k];
-      }
-      lastTs = sv.x;
-    }
-    if (have) {
-      if constexpr (REG) { T1 = T[1]; T2 = T[2]; }
-      else { T1 = TL(1); T2 = TL(2); }
-    }
-
-    // ---- the rest of the residual and one step of the Brent iteration on Tsurf (vic_surf_eval's body)
-    if (have) {
-      SurfEB eb;
-      {
-        unsigned long long tmp[CW_EBC];
-#pragma unroll
-        for (int w = 0; w < (int)CW_EBC; w++) tmp[w] = ebcl[w * 64 + lane];
-        __builtin_memcpy(static_cast<SurfEBConst*>(&eb), tmp, sizeof(SurfEBConst));
-      }
-      static_cast<SurfEBMut&>(eb) = mut;
-      const double fx = ok ? eb.eval(a.o, s3, sv.x, T1, T2) : ERROR_VAL;
-      mut = static_cast<const SurfEBMut&>(eb);
-      surf_solve_consume(a.o, sv, mut, fx);
-      if (sv.stage == SurfSolve::DONE) {
-        const CtxRef cx = CtxRef::at(a.ctx, a.ctx_words, hru);
-        ctx_put(cx, CO_SV, sv);
-        ctx_put(cx, CO_EBM, mut);
-        double* __restrict__ rec = a.pout + (size_t)hru * pout_hru_stride(Nn);
-        int* __restrict__ cnt = reinterpret_cast<int*>(rec + Nn + 1);
-#pragma unroll
-        for (int k = 0; k < NN; k++) {
-          if (k < Nn) {
-            if constexpr (REG) rec[k] = T[k];
-            else rec[k] = TL(k);
-            if (evcnt == 0) cnt[k] = cadd[k];
-            else cnt[k] += cadd[k];
-          }
-        }
-        rec[Nn] = __longlong_as_double((long long)((unsigned long long)fbmask | ((unsigned long long)(ok ? 1 : 0) << 32)));
-        a.hstate[hru] = 2;
-        have = false;
-      }
-    }
-  }
-#undef T0
-#undef TL
 }
 
 // ------------------------------------------------------------------------------------------------ glacier mass-balance fit
@@ -1093,6 +800,22 @@ __global__ __launch_bounds__(64) void vic_glacier_fit(const GArgs a) {
   }
   a.eq[(size_t)GMB_B0 * nc + c] = b0; a.eq[(size_t)GMB_B1 * nc + c] = b1; a.eq[(size_t)GMB_B2 * nc + c] = b2;
   a.eq[(size_t)GMB_FIT_ERROR * nc + c] = fit;
+}
+
+// ------------------------------------------------------------------------------------------------ derived cell rows
+__global__ __launch_bounds__(256) void vic_derive_cell_params(double* cp, int ncell, int Nn, int Nb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncell) return;
+  CellView cv{cp, ncell, c, Nn, Nb};
+#pragma unroll
+  for (int l = 0; l < VIC_NLAYER; l++) {
+    const SoilKLayer k = soil_conductivity_layer_constants(cv.lay(CPL_SOIL_DENS_MIN, l), cv.lay(CPL_BULK_DENS_MIN, l), cv.lay(CPL_QUARTZ, l),
+                                                           cv.lay(CPL_SOIL_DENSITY, l), cv.lay(CPL_BULK_DENSITY, l), cv.lay(CPL_ORGANIC, l));
+    cp[(size_t)VIC_CPX_ROW(CPX_KDRY, l, Nn, Nb) * ncell + c] = k.Kdry;
+    cp[(size_t)VIC_CPX_ROW(CPX_KSP, l, Nn, Nb) * ncell + c] = k.KsP;
+    cp[(size_t)VIC_CPX_ROW(CPX_KWP, l, Nn, Nb) * ncell + c] = k.KwP;
+    cp[(size_t)VIC_CPX_ROW(CPX_POROSITY, l, Nn, Nb) * ncell + c] = k.porosity;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ test hook
@@ -1231,8 +954,6 @@ struct vicgpu_ctx {
   int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr;
   int profile_waves = 0;           // resident waves of the profile kernel
   bool node_newton = false;        // frozen-node root finder: safeguarded Newton instead of the reference's Brent iteration
-  bool fused = true;               // one persistent kernel per Brent iteration on Tsurf (VICGPU_PIPELINE=rounds: kernel rounds)
-  int tsurf_waves = 0;             // resident waves of the fused kernel
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
 };
@@ -1308,26 +1029,6 @@ static int profile_resident_waves(int device, bool newton) {
   return per_cu * ncu;
 }
 
-template <int NN>
-static hipError_t launch_tsurf(const TArgs& ta, int nmax, int resident_waves, bool newton, hipStream_t st) {
-  int nblk = (nmax + 63) / 64;
-  if (nblk > resident_waves) nblk = resident_waves;      // persistent waves pull from the work list
-  if (nblk < 1) nblk = 1;                                // block 0 also clears the counters of the next list
-  if (newton) hipLaunchKernelGGL((vic_tsurf_solve<NN, true>), dim3(nblk), dim3(64), 0, st, ta);
-  else hipLaunchKernelGGL((vic_tsurf_solve<NN, false>), dim3(nblk), dim3(64), 0, st, ta);
-  return hipGetLastError();
-}
-
-template <int NN>
-static int tsurf_resident_waves(int device, bool newton) {
-  int per_cu = 0, ncu = 0;
-  hipError_t e = newton ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_tsurf_solve<NN, true>, 64, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vic_tsurf_solve<NN, false>, 64, 0);
-  if (e != hipSuccess || per_cu <= 0) per_cu = 2;
-  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
-  return per_cu * ncu;
-}
-
 #define CHKCH(ch, call)                                                                               \
   do {                                                                                                 \
     hipError_t e_ = (call);                                                                            \
@@ -1352,51 +1053,13 @@ static int fd_read_count(FdChunk* ch, int which, int* nsolve, int* nevalonly) {
   return VICGPU_OK;
 }
 
-// The fused form of a step: stage kernel -> { Tsurf solve kernel -> stage kernel } per snow sub-step.  Nothing is read back
-// unless the step has several sub-steps (then the number of HRUs that go on to the next one decides whether to stop early).
-static int fd_step_fused(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
-  const int Nn = c->o.Nnode;
-  const bool n10 = (Nn == 10);
-  hipStream_t st = ch->stream;
-  if (c->any_glacier) CHKCH(ch, (n10 ? launch_hru<10>(ka, st, false, true) : launch_hru<VIC_MAX_NODES>(ka, st, false, true)));
-  CHKCH(ch, hipMemsetAsync(ch->d_count, 0, sizeof(int) * CNT_TOTAL, st));
-  int cur = 0;
-  ka.cursor = ch->d_count + CNT_CURSOR;
-  ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET; ka.list_cap = ch->list_cap;
-  CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
-  TArgs ta;
-  ta.o = c->o; ta.ncell = c->ncell; ta.nhru = c->nhru; ta.Nn = Nn; ta.cell_params = c->d_cp; ta.hpi = c->d_hpi; ta.ctx = c->d_ctx;
-  ta.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
-  ta.pin = c->d_pin; ta.pout = c->d_pout; ta.hstate = c->d_hstate; ta.cap = ch->list_cap; ta.next = ch->d_count + CNT_CURSOR;
-  const int nsub = c->o.NF;
-  for (int p = 1; p <= nsub; p++) {
-    ta.list = ch->d_list[cur]; ta.count = ch->d_count + cur * NBUCKET; ta.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
-    CHKCH(ch, (n10 ? launch_tsurf<10>(ta, ch->gcount, c->tsurf_waves, c->node_newton, st)
-                   : launch_tsurf<VIC_MAX_NODES>(ta, ch->gcount, c->tsurf_waves, c->node_newton, st)));
-    cur ^= 1;
-    ch->rounds++;
-    ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET;
-    CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
-    if (p < nsub) {
-      int n = 0, ne = 0;
-      const int r = fd_read_count(ch, cur, &n, &ne);
-      if (r != VICGPU_OK) return r;
-      if (n == 0) break;
-    }
-  }
-  ch->steps++;
-  return VICGPU_OK;
-}
-
 static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
-  if (c->fused) return fd_step_fused(c, ch, ka);
   const int Nn = c->o.Nnode;
   const bool n10 = (Nn == 10);
   hipStream_t st = ch->stream;
   if (c->any_glacier) CHKCH(ch, (n10 ? launch_hru<10>(ka, st, false, true) : launch_hru<VIC_MAX_NODES>(ka, st, false, true)));
   CHKCH(ch, hipMemsetAsync(ch->d_count, 0, sizeof(int) * CNT_TOTAL, st));
   int cur = 0;
-  ka.cursor = nullptr;
   ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET; ka.list_cap = ch->list_cap;
   CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
   PArgs pa;
@@ -1625,8 +1288,9 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
   c->any_glacier = false;
   for (int g = 0; g < nhru; g++) if (hpi[(size_t)HPI_IS_GLACIER * nhru + g]) c->any_glacier = true;
   const size_t cp_n = (size_t)VICGPU_CP_NROW(c->opt.Nnode, c->opt.Nband) * ncell;
+  const size_t cpx_n = (size_t)VIC_CPX_NROW(c->opt.Nnode, c->opt.Nband) * ncell;      // + the derived rows
   const size_t sd_n = (size_t)VICGPU_SD_NROW(c->opt.Nnode) * nhru, si_n = (size_t)VICGPU_SI_NROW(c->opt.Nnode) * nhru;
-  HIPCHK(c, hipMalloc(&c->d_cp, sizeof(double) * cp_n));
+  HIPCHK(c, hipMalloc(&c->d_cp, sizeof(double) * cpx_n));
   HIPCHK(c, hipMalloc(&c->d_hpi, sizeof(int) * HPI_NROW * nhru));
   HIPCHK(c, hipMalloc(&c->d_hpd, sizeof(double) * HPD_NROW * nhru));
   HIPCHK(c, hipMalloc(&c->d_cell_off, sizeof(int) * (ncell + 1)));
@@ -1639,6 +1303,9 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
   HIPCHK(c, hipMalloc(&c->d_hru_err, sizeof(int) * nhru));
   HIPCHK(c, hipMalloc(&c->d_cell_err, sizeof(int) * ncell));
   HIPCHK(c, hipMemcpy(c->d_cp, cell_params, sizeof(double) * cp_n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(vic_derive_cell_params, dim3((ncell + 255) / 256), dim3(256), 0, c->stream, c->d_cp, ncell, c->opt.Nnode, c->opt.Nband);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->d_hpi, hpi, sizeof(int) * HPI_NROW * nhru, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_hpd, hpd, sizeof(double) * HPD_NROW * nhru, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_cell_off, cell_hru_offset, sizeof(int) * (ncell + 1), hipMemcpyHostToDevice));
@@ -1671,10 +1338,6 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
     if (const char* ev = getenv("VICGPU_NODE_SOLVER")) c->node_newton = (strcmp(ev, "newton") == 0);
     c->profile_waves = (Nn == 10) ? profile_resident_waves<10>(c->device, c->node_newton)
                                   : profile_resident_waves<VIC_MAX_NODES>(c->device, c->node_newton);
-    c->fused = true;
-    if (const char* ev = getenv("VICGPU_PIPELINE")) c->fused = (strcmp(ev, "rounds") != 0);
-    c->tsurf_waves = (Nn == 10) ? tsurf_resident_waves<10>(c->device, c->node_newton)
-                                : tsurf_resident_waves<VIC_MAX_NODES>(c->device, c->node_newton);
     // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  One chunk is the
     // default: the persistent profile kernel fills every SIMD, so concurrent chunks mostly queue behind each other.
     int nchunk = 1;
@@ -1778,7 +1441,7 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
   ka.glist = nullptr; ka.gcount = c->nhru;
   ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.pslot = c->d_pslot; ka.hstate = c->d_hstate; ka.hkey = c->d_hkey; ka.list = nullptr; ka.count = nullptr; ka.list_cap = 0;
-  ka.phase = 0; ka.cursor = nullptr;
+  ka.phase = 0;
   CArgs& ca = plan.ca;
   ca.ncell = c->ncell; ca.nhru = c->nhru; ca.c0 = 0; ca.ccount = c->ncell;
   ca.cell_off = c->d_cell_off; ca.cell_list = c->d_cell_list; ca.hpd = c->d_hpd;
