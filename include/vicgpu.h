@@ -360,7 +360,12 @@ enum {
   VICGPU_PURE_MAX_UNFROZEN_WATER, /* soil_conduction.c: T, max_moist, bubble, expt */
   VICGPU_PURE_LINEAR_INTERP,      /* x, lx, ux, ly, uy */
   VICGPU_PURE_VEG_HEIGHT,         /* calc_veg_params.c:26: displacement, L (NaN for L = 0) */
-  VICGPU_PURE_NFN
+  VICGPU_PURE_NFN,
+  /* device-only hook (no reference counterpart, not part of the golden vectors): soil_conductivity with the layer
+   * constants the library derives once per domain (cell 0): moist, Wu, layer.  Must equal VICGPU_PURE_SOIL_CONDUCTIVITY
+   * fed with that layer's parameters, bit for bit. */
+  VICGPU_PURE_SOIL_CONDUCTIVITY_DERIVED = VICGPU_PURE_NFN,
+  VICGPU_PURE_NFN_DEVICE
 };
 #define VICGPU_PURE_NIN 10
 int   vicgpu_debug_pure(vicgpu_ctx *ctx, int fn, int n, const double *in, double *out);

@@ -633,3 +633,28 @@ def test_node_solvers_agree_on_outputs(oracle_lib):
     Nn = 10
     dT = np.abs(sb[C["SD_NSCALAR"]:C["SD_NSCALAR"] + Nn] - sn[C["SD_NSCALAR"]:C["SD_NSCALAR"] + Nn]).max()
     print("node solvers: headline outputs agree to %.2e, node temperatures to %.2e K after %d free steps" % (w, dT, nsteps))
+
+
+def test_derived_cell_rows_reproduce_soil_conductivity():
+    """The library folds the soil-only factors of soil_conductivity (soil_conduction.c:7-105: Kdry, Ks^(1-porosity),
+    Kw^porosity) into derived rows of its device copy of the cell table, once per domain.  The folded form must give
+    exactly what the function itself gives with the layer's parameters -- bit for bit, on the device."""
+    from vic_amd.api import Model
+    opt = abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10)
+    d = domain.make_domain(3, opt, ntile=1)
+    m = Model(d)
+    rng = np.random.default_rng(5)
+    n = 512
+    for l in range(3):
+        lay = {k: d.cell_params[abi.cp_layer(C[k], l), 0] for k in ("CPL_SOIL_DENS_MIN", "CPL_BULK_DENS_MIN", "CPL_QUARTZ", "CPL_SOIL_DENSITY",
+                                                                    "CPL_BULK_DENSITY", "CPL_ORGANIC")}
+        moist = rng.uniform(0.0, 0.45, n)
+        moist[:8] = 0.0
+        Wu = np.where(rng.uniform(size=n) < 0.5, moist, moist * rng.uniform(0.05, 1.0, n))
+        a = np.zeros((n, 10)); a[:, 0] = moist; a[:, 1] = Wu
+        a[:, 2] = lay["CPL_SOIL_DENS_MIN"]; a[:, 3] = lay["CPL_BULK_DENS_MIN"]; a[:, 4] = lay["CPL_QUARTZ"]
+        a[:, 5] = lay["CPL_SOIL_DENSITY"]; a[:, 6] = lay["CPL_BULK_DENSITY"]; a[:, 7] = lay["CPL_ORGANIC"]
+        want = m.debug_pure(C["VICGPU_PURE_SOIL_CONDUCTIVITY"], a)
+        b = np.zeros((n, 10)); b[:, 0] = moist; b[:, 1] = Wu; b[:, 2] = l
+        got = m.debug_pure(C["VICGPU_PURE_SOIL_CONDUCTIVITY_DERIVED"], b)
+        assert np.array_equal(want, got), (l, np.abs(want - got).max())

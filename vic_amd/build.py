@@ -8,7 +8,13 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "vicgpu_api.hip")
 OUT = os.path.join(HERE, "libvicgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+# -ftrivial-auto-var-init=zero: every automatic variable has a defined value.  The big per-lane structs of the step
+# (StepConst, SurfEB, SurfSolve ...) are filled member by member and copied as a whole (parked context, sub-step hand-over),
+# so some copies move bytes that are still indeterminate (padding, members a branch has not set yet).  LLVM carries those as
+# `undef`; in the 512-register + scratch kernels (vic_hru_step, vic_fd_stage) hipcc 7.2 then emits scratch stores whose
+# source registers are partly undefined (the machine verifier reports them) and several builds computed
+# wrong numbers -- every one of them is correct, and identical for =zero and =pattern, once nothing is indeterminate.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-ftrivial-auto-var-init=zero",
          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
 
 

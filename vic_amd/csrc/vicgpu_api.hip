@@ -38,6 +38,20 @@ using namespace vic;
     }                                                                                                  \
   } while (0)
 
+// Host <-> device copies and fills of the set-up and read-back calls go through the context's own (non-blocking) stream
+// and are waited for there: a copy on the null stream is not ordered against kernels on a non-blocking stream, and a
+// pageable host-to-device copy may return before its last bytes have landed in device memory.
+static hipError_t copy_on(hipStream_t st, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return e;
+}
+static hipError_t fill_on(hipStream_t st, void* dst, int value, size_t bytes) {
+  hipError_t e = hipMemsetAsync(dst, value, bytes, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  return e;
+}
+
 struct KArgs {
   Opt o;
   int ncell, nhru, nveg_rows, write_fluxes;
@@ -408,6 +422,11 @@ VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView&
   Vc Ra, U, disp, zref, z0, ap[NPET];
 #pragma unroll
   for (int k = 0; k < NCASE; k++) { disp.v[k] = NAN; zref.v[k] = NAN; z0.v[k] = NAN; U.v[k] = NAN; Ra.v[k] = NAN; }
+#pragma unroll
+  for (int q = 0; q < NPET; q++) {
+#pragma unroll
+    for (int k = 0; k < NCASE; k++) ap[q].v[k] = NAN;
+  }
   bool overstory = false;
   const double rough = cv.s(CP_ROUGH), snow_rough = cv.s(CP_SNOW_ROUGH), wind = fc.v(VIC_F_WIND, o.NR);
 #pragma unroll 1
@@ -429,7 +448,14 @@ VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView&
     if (!calc_aerodynamic(overstory, height, vl.f(pet_idx, VL_TRUNK_RATIO), snow_rough, rough, vl.f(pet_idx, VL_WIND_ATTEN), Ra, U,
                           disp, zref, z0))
       err |= VICGPU_CELLERR_AERO;
-    if (p < NPET) ap[p] = Ra;
+    // ap[p] = Ra without a run-time index: hipcc 7.2's alloca-to-vector promotion mis-generated the dynamically indexed
+    // store of this 24-double array in several builds of vic_hru_step; a select per slot also keeps ap in
+    // registers by construction
+#pragma unroll
+    for (int q = 0; q < NPET; q++) {
+#pragma unroll
+      for (int k = 0; k < NCASE; k++) ap[q].v[k] = (p == q) ? Ra.v[k] : ap[q].v[k];
+    }
   }
 #pragma unroll
   for (int p = 0; p < NPET; p++) C.aero_pet[p] = ap[p];
@@ -693,24 +719,19 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
   const double* __restrict__ rec = a.pout + (size_t)g * pout_hru_stride(a.Nn);
   // the record the profile kernel has just written, or the one found on record for the final evaluation
-  int slot = sv.on_record ? sv.final_slot : a.pslot[g];
-  bool need_solve = false;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {
-    const double* __restrict__ po = rec + slot * pout_stride(a.Nn);
-    const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
-    if (sv.stage == SurfSolve::FINAL) sv.final_slot = slot;
-    const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
-    surf_solve_consume(a.o, sv, eb, fx);
-    need_solve = sv.stage != SurfSolve::DONE;
-    if (sv.stage != SurfSolve::FINAL) break;
-    // The root has been found: the final evaluation needs the profile at sv.x, which is on record if sv.x is one of the
-    // last two trial points (the same inputs give the same profile bit for bit).  Then the final evaluation is made right
-    // here, while the HRU's context is in registers, instead of in a round of its own.
-    if (rec[pout_key(a.Nn, slot)] == sv.x) sv.final_slot = slot;
-    else if (rec[pout_key(a.Nn, slot ^ 1)] == sv.x) { slot ^= 1; sv.final_slot = slot; }
-    else break;                                    // the solver fell back to a temperature it never evaluated: one more solve
-    sv.on_record = 1;
+  const int slot = sv.on_record ? sv.final_slot : a.pslot[g];
+  const double* __restrict__ po = rec + slot * pout_stride(a.Nn);
+  const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
+  if (sv.stage == SurfSolve::FINAL) sv.final_slot = slot;
+  const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
+  surf_solve_consume(a.o, sv, eb, fx);
+  bool need_solve = sv.stage != SurfSolve::DONE;
+  if (sv.stage == SurfSolve::FINAL) {
+    // the root has been found: the final evaluation needs the profile at sv.x, which is on record if sv.x is one of the
+    // last two trial points; the evaluation itself happens in the next round, together with everybody else's (making it
+    // here, in a second pass over eval(), costs the kernel 548 B of scratch per lane and 5 ms per step: measured, dropped)
+    if (rec[pout_key(a.Nn, slot)] == sv.x) { sv.final_slot = slot; sv.on_record = 1; need_solve = false; }
+    else if (rec[pout_key(a.Nn, slot ^ 1)] == sv.x) { sv.final_slot = slot ^ 1; sv.on_record = 1; need_solve = false; }
   }
   ctx_put(cx, CO_SV, sv);
   ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, (int)CW_EBM_FEED);
@@ -842,6 +863,12 @@ __global__ __launch_bounds__(64) void vic_debug_pure(const DArgs d) {
     case VICGPU_PURE_MAX_UNFROZEN_WATER: r = maximum_unfrozen_water(a[0], a[1], a[2], a[3]); break;
     case VICGPU_PURE_LINEAR_INTERP: r = linear_interp(a[0], a[1], a[2], a[3], a[4]); break;
     case VICGPU_PURE_VEG_HEIGHT: r = calc_veg_height(a[0], a[1]); break;
+    case VICGPU_PURE_SOIL_CONDUCTIVITY_DERIVED: {
+      const int l = (int)a[2];
+      const SoilKLayer kc{cv.x(CPX_KDRY, l), cv.x(CPX_KSP, l), cv.x(CPX_KWP, l), cv.x(CPX_POROSITY, l)};
+      r = soil_conductivity_pre(a[0], a[1], kc);
+      break;
+    }
     default: break;
   }
   d.out[i] = r;
@@ -1242,7 +1269,7 @@ int vicgpu_set_veglib(vicgpu_ctx* c, int nrow, const double* veglib) {
   HIPIGN(hipFree(c->d_veglib));
   c->d_veglib = nullptr;
   HIPCHK(c, hipMalloc(&c->d_veglib, sizeof(double) * nrow * VL_NFIELD));
-  HIPCHK(c, hipMemcpy(c->d_veglib, veglib, sizeof(double) * nrow * VL_NFIELD, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_on(c->stream, c->d_veglib, veglib, sizeof(double) * nrow * VL_NFIELD, hipMemcpyHostToDevice));
   c->nveg_rows = nrow;
   return VICGPU_OK;
 }
@@ -1302,21 +1329,21 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
   HIPCHK(c, hipMalloc(&c->d_accum, sizeof(double) * CA_NROW * ncell));
   HIPCHK(c, hipMalloc(&c->d_hru_err, sizeof(int) * nhru));
   HIPCHK(c, hipMalloc(&c->d_cell_err, sizeof(int) * ncell));
-  HIPCHK(c, hipMemcpy(c->d_cp, cell_params, sizeof(double) * cp_n, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_on(c->stream, c->d_cp, cell_params, sizeof(double) * cp_n, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(vic_derive_cell_params, dim3((ncell + 255) / 256), dim3(256), 0, c->stream, c->d_cp, ncell, c->opt.Nnode, c->opt.Nband);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->d_hpi, hpi, sizeof(int) * HPI_NROW * nhru, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->d_hpd, hpd, sizeof(double) * HPD_NROW * nhru, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->d_cell_off, cell_hru_offset, sizeof(int) * (ncell + 1), hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->d_cell_list, cell_hru_list, sizeof(int) * nhru, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemset(c->d_sd, 0, sizeof(double) * sd_n));
-  HIPCHK(c, hipMemset(c->d_si, 0, sizeof(int) * si_n));
-  HIPCHK(c, hipMemset(c->d_flux, 0, sizeof(double) * FX_NROW * nhru));
-  HIPCHK(c, hipMemset(c->d_cell_out, 0, sizeof(double) * CO_NROW * ncell));
-  HIPCHK(c, hipMemset(c->d_accum, 0, sizeof(double) * CA_NROW * ncell));
-  HIPCHK(c, hipMemset(c->d_hru_err, 0, sizeof(int) * nhru));
-  HIPCHK(c, hipMemset(c->d_cell_err, 0, sizeof(int) * ncell));
+  HIPCHK(c, copy_on(c->stream, c->d_hpi, hpi, sizeof(int) * HPI_NROW * nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_on(c->stream, c->d_hpd, hpd, sizeof(double) * HPD_NROW * nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_on(c->stream, c->d_cell_off, cell_hru_offset, sizeof(int) * (ncell + 1), hipMemcpyHostToDevice));
+  HIPCHK(c, copy_on(c->stream, c->d_cell_list, cell_hru_list, sizeof(int) * nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, fill_on(c->stream, c->d_sd, 0, sizeof(double) * sd_n));
+  HIPCHK(c, fill_on(c->stream, c->d_si, 0, sizeof(int) * si_n));
+  HIPCHK(c, fill_on(c->stream, c->d_flux, 0, sizeof(double) * FX_NROW * nhru));
+  HIPCHK(c, fill_on(c->stream, c->d_cell_out, 0, sizeof(double) * CO_NROW * ncell));
+  HIPCHK(c, fill_on(c->stream, c->d_accum, 0, sizeof(double) * CA_NROW * ncell));
+  HIPCHK(c, fill_on(c->stream, c->d_hru_err, 0, sizeof(int) * nhru));
+  HIPCHK(c, fill_on(c->stream, c->d_cell_err, 0, sizeof(int) * ncell));
   c->fd = !c->o.QUICK_FLUX;
   if (c->fd) {
     const int Nn = c->o.Nnode;
@@ -1327,12 +1354,12 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
     HIPCHK(c, hipMalloc(&c->d_pout, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
     HIPCHK(c, hipMalloc(&c->d_pslot, sizeof(int) * nhru));
     HIPCHK(c, hipMalloc(&c->d_hkey, sizeof(int) * nhru));
-    HIPCHK(c, hipMemset(c->d_hkey, 0, sizeof(int) * nhru));
-    HIPCHK(c, hipMemset(c->d_pslot, 0, sizeof(int) * nhru));
+    HIPCHK(c, fill_on(c->stream, c->d_hkey, 0, sizeof(int) * nhru));
+    HIPCHK(c, fill_on(c->stream, c->d_pslot, 0, sizeof(int) * nhru));
     HIPCHK(c, hipMalloc(&c->d_hstate, sizeof(int) * nhru));
-    HIPCHK(c, hipMemset(c->d_hstate, 0, sizeof(int) * nhru));
-    HIPCHK(c, hipMemset(c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
-    HIPCHK(c, hipMemset(c->d_pout, 0, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
+    HIPCHK(c, fill_on(c->stream, c->d_hstate, 0, sizeof(int) * nhru));
+    HIPCHK(c, fill_on(c->stream, c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
+    HIPCHK(c, fill_on(c->stream, c->d_pout, 0, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
     // frozen-node root finder (vic_profile.hpp): the option, overridable for A/B runs
     c->node_newton = c->opt.NODE_SOLVER == VIC_NODE_SOLVER_NEWTON;
     if (const char* ev = getenv("VICGPU_NODE_SOLVER")) c->node_newton = (strcmp(ev, "newton") == 0);
@@ -1360,7 +1387,7 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
       HIPCHK(c, hipMalloc(&ch.d_list[1], gb * NBUCKET));
       HIPCHK(c, hipMalloc(&ch.d_count, sizeof(int) * CNT_TOTAL));
       HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * CNT_TOTAL * 2, hipHostMallocDefault));
-      if (ch.gcount) HIPCHK(c, hipMemcpy(ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
+      if (ch.gcount) HIPCHK(c, copy_on(c->stream, ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
       HIPCHK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
       HIPCHK(c, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
       for (hipEvent_t& e : ch.readback) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1374,8 +1401,8 @@ int vicgpu_set_state(vicgpu_ctx* c, const double* sd, const int* si) {
   if (!c->domain_ready) return VICGPU_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->d_sd, sd, sizeof(double) * VICGPU_SD_NROW(c->opt.Nnode) * c->nhru, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->d_si, si, sizeof(int) * VICGPU_SI_NROW(c->opt.Nnode) * c->nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_on(c->stream, c->d_sd, sd, sizeof(double) * VICGPU_SD_NROW(c->opt.Nnode) * c->nhru, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_on(c->stream, c->d_si, si, sizeof(int) * VICGPU_SI_NROW(c->opt.Nnode) * c->nhru, hipMemcpyHostToDevice));
   return VICGPU_OK;
 }
 
@@ -1384,8 +1411,8 @@ int vicgpu_get_state(vicgpu_ctx* c, double* sd, int* si) {
   if (!c->domain_ready) return VICGPU_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(sd, c->d_sd, sizeof(double) * VICGPU_SD_NROW(c->opt.Nnode) * c->nhru, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(si, c->d_si, sizeof(int) * VICGPU_SI_NROW(c->opt.Nnode) * c->nhru, hipMemcpyDeviceToHost));
+  HIPCHK(c, copy_on(c->stream, sd, c->d_sd, sizeof(double) * VICGPU_SD_NROW(c->opt.Nnode) * c->nhru, hipMemcpyDeviceToHost));
+  HIPCHK(c, copy_on(c->stream, si, c->d_si, sizeof(int) * VICGPU_SI_NROW(c->opt.Nnode) * c->nhru, hipMemcpyDeviceToHost));
   return VICGPU_OK;
 }
 
@@ -1519,7 +1546,7 @@ static int d2h(vicgpu_ctx* c, void* dst, const void* src, size_t bytes) {
   if (!c || !dst || !src) return VICGPU_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(c, copy_on(c->stream, dst, src, bytes, hipMemcpyDeviceToHost));
   return VICGPU_OK;
 }
 
@@ -1547,25 +1574,25 @@ int vicgpu_glacier_mass_balance_fit(vicgpu_ctx* c, double* eq, int reset) {
   hipLaunchKernelGGL(vic_glacier_fit, dim3((c->ncell + 63) / 64), dim3(64), 0, c->stream, g);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e == hipSuccess) e = hipMemcpy(eq, d_eq, sizeof(double) * GMB_NROW * c->ncell, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = copy_on(c->stream, eq, d_eq, sizeof(double) * GMB_NROW * c->ncell, hipMemcpyDeviceToHost);
   HIPIGN(hipFree(d_eq));
   HIPCHK(c, e);
   return VICGPU_OK;
 }
 
 int vicgpu_debug_pure(vicgpu_ctx* c, int fn, int n, const double* in, double* out) {
-  if (!c || !c->d_cp || fn < 0 || fn >= VICGPU_PURE_NFN || n <= 0 || !in || !out) return VICGPU_ERR_ARG;
+  if (!c || !c->d_cp || fn < 0 || fn >= VICGPU_PURE_NFN_DEVICE || n <= 0 || !in || !out) return VICGPU_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   double *d_in = nullptr, *d_out = nullptr;
   HIPCHK(c, hipMalloc(&d_in, sizeof(double) * (size_t)n * VICGPU_PURE_NIN));
   HIPCHK(c, hipMalloc(&d_out, sizeof(double) * (size_t)n));
-  HIPCHK(c, hipMemcpy(d_in, in, sizeof(double) * (size_t)n * VICGPU_PURE_NIN, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_on(c->stream, d_in, in, sizeof(double) * (size_t)n * VICGPU_PURE_NIN, hipMemcpyHostToDevice));
   DArgs d;
   d.o = c->o; d.cell_params = c->d_cp; d.ncell = c->ncell; d.fn = fn; d.n = n; d.in = d_in; d.out = d_out;
   hipLaunchKernelGGL(vic_debug_pure, dim3((n + 63) / 64), dim3(64), 0, c->stream, d);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e == hipSuccess) e = hipMemcpy(out, d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = copy_on(c->stream, out, d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
   HIPIGN(hipFree(d_in)); HIPIGN(hipFree(d_out));
   HIPCHK(c, e);
   return VICGPU_OK;
