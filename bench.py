@@ -1,10 +1,18 @@
 #!/usr/bin/env python3
 """Benchmark of the VIC hot path (dist_prec -> full_energy -> surface_fluxes) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg4|cfg2] [--compat]
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg4|cfg2] [--compat] [--node-solver newton|brent]
 
-A "step" is one model time step of every cell of the rank's shard (all HRUs, all snow sub-steps).
+A "step" is one model time step of every cell of the rank's shard (all HRUs, all snow sub-steps) INCLUDING its put_data
+(dist_prec.c:167): the aggregated output variables are updated on the device every step, and the table the writer needs
+(OUT_VARS, daily aggregates as float32) is fetched once after the timed region -- that fetch, plus the all-gather of it
+at N > 1, is `output_gather_ms`.
 Metric: cell-timesteps/s, whole job (sum over ranks).
+
+Node solver.  The frozen-node root finds of the soil profile run as a safeguarded Newton iteration by default (outputs
+within north_star's 1e-5 of the reference: tests/test_gpu_parity.py::test_gpu_against_reference_goldens[*-newton]);
+`--node-solver brent` replays the reference's Brent iteration step by step (1e-6 on every state variable).  At N = 1 the
+JSON line also carries the step time of the other mode (`strict_replay_ms_per_step`), measured after the timed region.
 
 Launching.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (one process per GPU,
 `python -m torch.distributed.run --nproc-per-node N ...`, RCCL) BEFORE anything in this process touches the GPU, waits
@@ -37,6 +45,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CELLS_PER_GPU_CFG4 = 125000
+OUT_STEP_RATIO = 24     # hourly steps, daily output records
+# the variables north_star names (runoff, baseflow, SWE, soil moisture [3 layers], glacier mass balance) + evaporation and
+# precipitation: what the writer gets per output record
+OUT_VARS = ["OUT_RUNOFF", "OUT_BASEFLOW", "OUT_SWE", "OUT_SOIL_MOIST", "OUT_GLAC_MBAL", "OUT_EVAP", "OUT_PREC"]
 
 
 def config(name, compat=False):
@@ -59,7 +71,7 @@ def config(name, compat=False):
     raise SystemExit("unknown config " + name)
 
 
-def b_alg(opt, hru_per_cell, n_outvar=8, out_step_ratio=24):
+def b_alg(opt, hru_per_cell, n_outvar=9, out_step_ratio=OUT_STEP_RATIO):
     """Algorithmic bytes per cell-step, SURVEY.md 8(d):
     8*NVAR_F + P_cell + sum_hru(2*S_hru + 64) + B_out with S_hru = 8*(30+Nn), P_cell = 8*(77+8*Nn+5*Nband+110)."""
     Nn, Nb = opt.Nnode, opt.Nband
@@ -101,10 +113,11 @@ def cpu_baseline(cfg, target_seconds=15.0):
 
 
 def csrc_digest():
-    """Content hash of the device sources + ABI header: the build a committed profile belongs to (the GPU box has no .git)."""
+    """Content hash of the device sources + ABI headers: the build a committed profile belongs to (the GPU box has no .git)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "vic_amd", "csrc")
-    for fn in sorted(os.listdir(d)) + [os.path.join(ROOT, "include", "vicgpu.h")]:
+    inc = os.path.join(ROOT, "include")
+    for fn in sorted(os.listdir(d)) + [os.path.join(inc, x) for x in sorted(os.listdir(inc))]:
         with open(fn if os.path.isabs(fn) else os.path.join(d, fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -164,6 +177,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", default=None, help="cfg3 (default at 1 GPU), cfg4 (default at > 1 GPU), cfg2")
     ap.add_argument("--compat", action="store_true", help="FROZEN_SOIL as the reference ships it (frozen_soil.c:218-221) instead of 'fixed'")
+    ap.add_argument("--node-solver", default="newton", choices=["newton", "brent"],
+                    help="frozen-node root finder (vicgpu_options.NODE_SOLVER): converged Newton (default) or the reference's Brent iteration replayed")
+    ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timing with the other node solver (N = 1)")
     ap.add_argument("--ncell", type=int, default=0, help="override cells per GPU (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -201,6 +217,7 @@ def main():
     cfg_name = args.config or ("cfg3" if world == 1 else "cfg4")
     cfg = config(cfg_name, compat=args.compat)
     opt = cfg["opt"]
+    opt.NODE_SOLVER = C["VIC_NODE_SOLVER_NEWTON"] if args.node_solver == "newton" else C["VIC_NODE_SOLVER_BRENT"]
     ncell = args.ncell or cfg["ncell"]
     K, W = args.steps, args.warmup
     # ONE domain of world x ncell cells, cut into contiguous HRU-balanced blocks (shard.partition_cells: every cell has the
@@ -214,12 +231,17 @@ def main():
         # the driver opens the glacier mass-balance accumulation window (accumulateGlacierMassBalance.c:13-67)
         isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
         sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
-    m = Model(d, device=local_rank)
-    m.set_state(sd0, si0)
-    m.set_write_fluxes(False)          # production setting: per-cell outputs only, no per-HRU flux table
-    m.push_forcing(f, sf, dmy)
-    m.synchronize()
-    del f
+    def make_model(dom):
+        mm = Model(dom, device=local_rank)
+        mm.set_state(sd0, si0)
+        mm.set_write_fluxes(False)     # production setting: nobody reads the per-HRU flux table on the host ...
+        mm.put_data_config(OUT_STEP_RATIO)   # ... put_data does, on the device (this turns its rows back on inside the step)
+        mm.put_data_init()
+        mm.push_forcing(f, sf, dmy)
+        mm.synchronize()
+        return mm
+
+    m = make_model(d)
 
     def barrier():
         torch.cuda.synchronize()
@@ -243,20 +265,41 @@ def main():
     kernel_ms, nlaunch = m.last_kernel_ms()
     nerr = int((m.get_cell_errors() != 0).sum())
     acc = m.get_accum()
-    gather_ms = None
+    # the writer's table: the aggregates of OUT_VARS as float32 [rows][cells] (WriteOutputNetCDF.c:387-455), fetched once per
+    # output record -- outside the timed region (it happens every OUT_STEP_RATIO steps, not per model step)
+    barrier()
+    tg = time.perf_counter()
+    outs = m.get_outputs(OUT_VARS, reset=True)
+    full = outs
     if use_dist:
-        # the one exchange of the path: the per-cell output table to the writer, RCCL all-gather over xGMI;
-        # outside the timed region (it happens once per output step, not per model step)
-        barrier()
-        tg = time.perf_counter()
-        full = shard.gather_cell_table(acc, [ncell] * world, device=torch.device("cuda", local_rank))
-        barrier()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        assert full.shape == (acc.shape[0], ncell_global)
-        assert np.array_equal(full[:, c0:c1], acc, equal_nan=True)          # this rank's block arrived where the writer expects it
+        # the one exchange of the path: that table to the writer, RCCL all-gather over xGMI
+        full = shard.gather_cell_table(outs, [ncell] * world, device=torch.device("cuda", local_rank))
+    barrier()
+    gather_ms = (time.perf_counter() - tg) * 1e3
+    assert full.shape == (outs.shape[0], ncell_global) and full.dtype == np.float32
+    assert np.array_equal(full[:, c0:c1], outs, equal_nan=True)              # this rank's block arrived where the writer expects it
+    if use_dist:
         nerr_t = torch.tensor([nerr], device="cuda", dtype=torch.int64)
         dist.all_reduce(nerr_t)
         nerr = int(nerr_t.item())
+    # the same K steps with the other node solver (N = 1): what the choice of solver costs / buys
+    other_ms = None
+    if world == 1 and not opt.QUICK_FLUX and not args.no_strict_leg:
+        import copy
+        d2 = copy.copy(d)
+        d2.opt = copy.copy(opt)
+        d2.opt.NODE_SOLVER = C["VIC_NODE_SOLVER_BRENT"] if args.node_solver == "newton" else C["VIC_NODE_SOLVER_NEWTON"]
+        m.close()
+        m2 = make_model(d2)
+        if W > 0:
+            m2.dist_prec(0, W, sync=True)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        m2.dist_prec(W, K, sync=True)
+        torch.cuda.synchronize()
+        other_ms = (time.perf_counter() - ts) / K * 1e3
+        m2.close()
+    del f
 
     if rank == 0:
         hru_per_cell = d.nhru // d.ncell
@@ -264,7 +307,7 @@ def main():
         value = world * ncell * K / elapsed
         achieved = balg * ncell / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_note = measured_traffic(cfg_name, ncell, args.compat)
-        mean_all = full if use_dist else acc
+        row = {n: i for i, n in enumerate(["OUT_RUNOFF", "OUT_BASEFLOW", "OUT_SWE"])}
         out = {
             "metric": "cell-timesteps/s", "value": value, "unit": "cell-timesteps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -273,9 +316,13 @@ def main():
                        "frozen_soil_semantics": ("compat" if opt.frozen_compat else "fixed") if opt.FROZEN_SOIL else None,
                        "parallelism": "cells sharded across %d GPU(s) (one process per GPU, contiguous blocks of one domain), no data-path collective" % world,
                        "ranks_seen_by_rccl": ranks_seen if use_dist else None,
+                       "node_solver": args.node_solver,
+                       ("strict_replay_ms_per_step" if args.node_solver == "newton" else "newton_ms_per_step"): other_ms,
+                       "put_data": "on device every step (vic_put_data), out_step_ratio %d" % OUT_STEP_RATIO,
+                       "output_table": "%s as float32 [%d][%d]" % (",".join(OUT_VARS), full.shape[0], full.shape[1]),
                        "cells_with_error_flags": nerr, "output_gather_ms": gather_ms,
-                       "mean_runoff_mm_per_step": float(mean_all[C["CA_RUNOFF"]].mean() / max(1, K)),
-                       "mean_swe_mm_end": float(mean_all[C["CA_SWE_END"]].mean())},
+                       "mean_runoff_mm_per_step": float(full[row["OUT_RUNOFF"]].mean() / max(1, K)),
+                       "mean_swe_mm_end": float(full[row["OUT_SWE"]].mean())},
             # one "launch" of the hot path = one model step of the rank's cells: the QUICK_FLUX path is a single kernel, the
             # finite-difference path a pipeline of kernels (stage / profile solve / surface evaluation); the duration is
             # measured with HIP events on the library's streams around the whole step

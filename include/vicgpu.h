@@ -253,6 +253,10 @@ enum {
   FX_GLAC_MASS_BALANCE, FX_GLAC_ICE_MASS_BALANCE, FX_GLAC_ACCUMULATION, FX_GLAC_MELT, FX_GLAC_VAPOR_FLUX,
   FX_GLAC_INFLOW, FX_GLAC_OUTFLOW, FX_GLAC_OUTFLOW_COEF, FX_GLAC_QNET, FX_GLAC_COLD_CONTENT,
   FX_GLACIER_FLUX, FX_DELTACC_GLAC, FX_GLACIER_MELT_ENERGY,
+  /* read by put_data only: frost / thaw front depths (energy.fdepth/tdepth, m; NaN = no such front) and the per-layer
+   * water table (layer[l].zwt, cm).  Like every row here they are rewritten by the step for the HRUs it computes; for
+   * HRUs whose step does not produce them (glacier HRUs have no soil column step) they keep what vicgpu_set_fluxes gave */
+  FX_FDEPTH0, FX_FDEPTH1, FX_FDEPTH2, FX_TDEPTH0, FX_TDEPTH1, FX_TDEPTH2, FX_ZWTL0, FX_ZWTL1, FX_ZWTL2,
   FX_NROW
 };
 

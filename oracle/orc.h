@@ -146,7 +146,7 @@ typedef struct {
          water_storage, outflow, outflow_coef, inflow;
 } orc_glac;
 
-typedef struct {
+typedef struct orc_hru_s {
   /* parameters */
   int cell, band, veg_index, veg_class, is_glacier, is_artificial_bare;
   double Cv, root[3];
@@ -171,6 +171,19 @@ typedef struct {
    * the reference's own stopping error from implementation error when the product's Newton node solver is checked. */
   double node_macheps, node_ttol;
 } orc_model;
+
+/* handle behind the vicorc_* entry points (orc_driver.c, orc_putdata.c) */
+typedef struct {
+  orc_model model;
+  int ncell, nhru;
+  double *veglib;
+  orc_soil *soil;
+  struct orc_hru_s *hru;
+  int *cell_off, *cell_list;
+  /* put_data (orc_putdata.c): OutputData.data / .aggdata of every provided variable, [row][cell], and the per-cell
+   * bookkeeping rows of include/vicgpu_out.h */
+  double *out_data, *out_agg, *pb;
+} vicorc_handle;
 
 static inline const double *orc_veg(const orc_model *m, int idx) { return m->veglib + (size_t)idx * VL_NFIELD; }
 

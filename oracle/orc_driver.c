@@ -406,14 +406,6 @@ int orc_full_energy(const orc_model *m, const orc_soil *sc, orc_atmos *atmos, co
 
 /* ============================================================ table <-> struct and the C entry points */
 
-typedef struct {
-  orc_model model;
-  int ncell, nhru;
-  double *veglib;
-  orc_soil *soil;
-  orc_hru *hru;
-  int *cell_off, *cell_list;
-} vicorc_handle;
 
 #define CPV(row) cp[(size_t)(row) * ncell + c]
 
@@ -433,7 +425,8 @@ void *vicorc_create(const vicgpu_options *opt) {
 void vicorc_destroy(void *hv) {
   vicorc_handle *h = (vicorc_handle *)hv;
   if (!h) return;
-  free(h->veglib); free(h->soil); free(h->hru); free(h->cell_off); free(h->cell_list); free(h);
+  free(h->veglib); free(h->soil); free(h->hru); free(h->cell_off); free(h->cell_list);
+  free(h->out_data); free(h->out_agg); free(h->pb); free(h);
 }
 
 int vicorc_set_veglib(void *hv, int nrow, const double *t) {
@@ -522,6 +515,7 @@ int vicorc_set_domain(void *hv, int ncell, int nhru, const double *cp, const int
 #define SDP(row) sd[(size_t)(row) * nh + g]
 #define SIP(row) si[(size_t)(row) * nh + g]
 
+int vicorc_get_fluxes(void *hv, double *fx);
 int vicorc_get_state(void *hv, double *sd, int *si) {
   vicorc_handle *h = (vicorc_handle *)hv;
   const int Nn = h->model.opt.Nnode; const size_t nh = h->nhru;
@@ -622,6 +616,7 @@ static void export_flux(vicorc_handle *h, double *fx) {
     FXP(FX_SNOW_VAPOR_FLUX) = s->vapor_flux; FXP(FX_SNOW_CANOPY_VAPOR_FLUX) = s->canopy_vapor_flux;
     FXP(FX_SNOW_BLOWING_FLUX) = s->blowing_flux; FXP(FX_SNOW_SURFACE_FLUX) = s->surface_flux; FXP(FX_SNOW_MELT) = s->melt;
     FXP(FX_SNOW_MASS_ERROR) = s->mass_error; FXP(FX_SNOW_QNET) = s->Qnet;
+    for (l = 0; l < 3; l++) { FXP(FX_FDEPTH0 + l) = e->fdepth[l]; FXP(FX_TDEPTH0 + l) = e->tdepth[l]; FXP(FX_ZWTL0 + l) = u->layer[l].zwt; }
     for (p = 0; p < 6; p++) FXP(FX_POT_EVAP0 + p) = u->pot_evap[p];
     FXP(FX_AERO_RESIST_SURFACE) = u->aero_resist_surface; FXP(FX_AERO_RESIST_OVERSTORY) = u->aero_resist_overstory;
     FXP(FX_ROOTMOIST) = u->rootmoist; FXP(FX_WETNESS) = u->wetness; FXP(FX_ZWT) = u->zwt; FXP(FX_ZWT2) = u->zwt2; FXP(FX_ZWT3) = u->zwt3;
@@ -637,6 +632,35 @@ static void export_flux(vicorc_handle *h, double *fx) {
     FXP(FX_GLACIER_FLUX) = e->glacier_flux; FXP(FX_DELTACC_GLAC) = e->deltaCC_glac; FXP(FX_GLACIER_MELT_ENERGY) = e->glacier_melt_energy;
 #undef FXP
   }
+}
+
+/* the per-HRU values put_data reads that a step may leave untouched (initialize_model_state results, glacier HRUs' soil
+ * diagnostics): taken from a flux table [FX_NROW][nhru] */
+int vicorc_set_fluxes(void *hv, const double *fx) {
+  vicorc_handle *h = (vicorc_handle *)hv;
+  const size_t nh = h->nhru;
+  int g, l, p;
+  for (g = 0; g < h->nhru; g++) {
+    orc_hru *u = &h->hru[g]; orc_energy *e = &u->energy; orc_snow *s = &u->snow;
+#define FXP(row) fx[(size_t)(row) * nh + g]
+    u->runoff = FXP(FX_RUNOFF); u->baseflow = FXP(FX_BASEFLOW); u->asat = FXP(FX_ASAT); u->inflow = FXP(FX_INFLOW);
+    for (l = 0; l < 3; l++) u->layer[l].evap = FXP(FX_EVAP0 + l);
+    u->veg.canopyevap = FXP(FX_CANOPYEVAP); u->veg.throughfall = FXP(FX_THROUGHFALL);
+    s->vapor_flux = FXP(FX_SNOW_VAPOR_FLUX); s->canopy_vapor_flux = FXP(FX_SNOW_CANOPY_VAPOR_FLUX);
+    s->blowing_flux = FXP(FX_SNOW_BLOWING_FLUX); s->surface_flux = FXP(FX_SNOW_SURFACE_FLUX); s->melt = FXP(FX_SNOW_MELT);
+    for (l = 0; l < 3; l++) { e->fdepth[l] = FXP(FX_FDEPTH0 + l); e->tdepth[l] = FXP(FX_TDEPTH0 + l); u->layer[l].zwt = FXP(FX_ZWTL0 + l); }
+    for (p = 0; p < 6; p++) u->pot_evap[p] = FXP(FX_POT_EVAP0 + p);
+    u->aero_resist_surface = FXP(FX_AERO_RESIST_SURFACE); u->aero_resist_overstory = FXP(FX_AERO_RESIST_OVERSTORY);
+    u->rootmoist = FXP(FX_ROOTMOIST); u->wetness = FXP(FX_WETNESS); u->zwt = FXP(FX_ZWT); u->zwt2 = FXP(FX_ZWT2); u->zwt3 = FXP(FX_ZWT3);
+    e->AtmosLatent = FXP(FX_ATMOS_LATENT); e->AtmosLatentSub = FXP(FX_ATMOS_LATENT_SUB); e->AtmosSensible = FXP(FX_ATMOS_SENSIBLE);
+    e->LongUnderIn = FXP(FX_LONG_UNDER_IN); e->NetLongAtmos = FXP(FX_NET_LONG_ATMOS); e->NetShortAtmos = FXP(FX_NET_SHORT_ATMOS);
+    u->glac.mass_balance = FXP(FX_GLAC_MASS_BALANCE); u->glac.ice_mass_balance = FXP(FX_GLAC_ICE_MASS_BALANCE);
+    u->glac.accumulation = FXP(FX_GLAC_ACCUMULATION); u->glac.melt = FXP(FX_GLAC_MELT); u->glac.vapor_flux = FXP(FX_GLAC_VAPOR_FLUX);
+    u->glac.inflow = FXP(FX_GLAC_INFLOW); u->glac.outflow = FXP(FX_GLAC_OUTFLOW); u->glac.outflow_coef = FXP(FX_GLAC_OUTFLOW_COEF);
+    e->glacier_flux = FXP(FX_GLACIER_FLUX); e->deltaCC_glac = FXP(FX_DELTACC_GLAC); e->glacier_melt_energy = FXP(FX_GLACIER_MELT_ENERGY);
+#undef FXP
+  }
+  return 0;
 }
 
 /* one model step for all cells; same contract as vicref_step (oracle/ref_build/vicref_shim.cpp) */
@@ -683,6 +707,8 @@ int vicorc_step(void *hv, const double *forcing, const unsigned char *snowflag, 
   if (flux) export_flux(h, flux);
   return nerr;
 }
+
+int vicorc_get_fluxes(void *hv, double *fx) { export_flux((vicorc_handle *)hv, fx); return 0; }
 
 double vicorc_run(void *hv, int nsteps, const double *forcing, const unsigned char *snowflag, const int *dmyv, int nthreads) {
   vicorc_handle *h = (vicorc_handle *)hv;

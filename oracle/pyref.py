@@ -123,6 +123,32 @@ class _Model:
         assert rc == 0, rc
         return out
 
+    # ---- put_data (oracle/orc_putdata.c, the reference's put_data.c through the shim)
+    def get_fluxes(self):
+        fx = np.zeros((C["FX_NROW"], self.dom.nhru))
+        f = getattr(self.lib, self.prefix + "get_fluxes"); f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, _dp]
+        assert f(self.h, _d(fx)) == 0
+        return fx
+
+    def put_data(self, rec, forcing=None, cell_out=None, out_step_ratio=1):
+        """put_data for every cell after a step (rec >= 0) or the initialisation call before the first one (rec < 0)."""
+        f = getattr(self.lib, self.prefix + "put_data"); f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, _dp, ctypes.c_int]
+        forcing = None if forcing is None else np.ascontiguousarray(forcing)
+        cell_out = None if cell_out is None else np.ascontiguousarray(cell_out)
+        rc = f(self.h, int(rec), _d(forcing), _d(cell_out), int(out_step_ratio))
+        assert rc == 0, rc
+
+    def get_balance(self):
+        pb = np.zeros((C["PB_NROW"], self.dom.ncell))
+        f = getattr(self.lib, self.prefix + "get_balance"); f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, _dp]
+        assert f(self.h, _d(pb)) == 0
+        return pb
+
+    def reset_agg(self):
+        f = getattr(self.lib, self.prefix + "reset_agg"); f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p]
+        assert f(self.h) == 0
+
     def run(self, forcing, snowflag, dmy, nthreads=1):
         forcing = np.ascontiguousarray(forcing); snowflag = np.ascontiguousarray(snowflag)
         dmy = np.ascontiguousarray(dmy, dtype=np.int32)
@@ -150,6 +176,26 @@ class RefModel(_Model):
         self.lib.vicref_get_cell_params(self.h, _d(out))
         return out
 
+    def output_list(self):
+        """The reference's own output variable list: {name: (index, nelem, aggtype)} (create_output_list)."""
+        self.lib.vicref_out_nvar.restype = ctypes.c_int
+        f = self.lib.vicref_out_info; f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, _ip, _ip]
+        out = {}
+        for v in range(self.lib.vicref_out_nvar()):
+            name = ctypes.create_string_buffer(64); ne = ctypes.c_int(0); ag = ctypes.c_int(0)
+            assert f(self.h, v, name, ctypes.byref(ne), ctypes.byref(ag)) == 0
+            out[name.value.decode()] = (v, ne.value, ag.value)
+        return out
+
+    def get_output(self, name, agg=False):
+        """OutputData.data (or .aggdata) of a variable of the reference's list by name: [nelem][ncell]."""
+        v, ne, _ = self.output_list()[name]
+        out = np.zeros((ne, self.dom.ncell))
+        f = self.lib.vicref_get_output; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
+        assert f(self.h, v, int(agg), _d(out)) == ne
+        return out
+
 
 class OracleModel(_Model):
     prefix = "vicorc_"
@@ -163,6 +209,40 @@ class OracleModel(_Model):
             lib.vicorc_set_node_tolerance.restype = ctypes.c_int
             lib.vicorc_set_node_tolerance.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double]
             assert lib.vicorc_set_node_tolerance(self.h, 1e-16, 1e-13) == 0
+
+
+def _orc_out(self):
+    self.lib.vicorc_out_var_id.restype = ctypes.c_int; self.lib.vicorc_out_var_id.argtypes = [ctypes.c_char_p]
+    self.lib.vicorc_out_var_nelem.restype = ctypes.c_int; self.lib.vicorc_out_var_nelem.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    self.lib.vicorc_out_var_agg.restype = ctypes.c_int; self.lib.vicorc_out_var_agg.argtypes = [ctypes.c_int]
+    self.lib.vicorc_out_var_name.restype = ctypes.c_char_p; self.lib.vicorc_out_var_name.argtypes = [ctypes.c_int]
+    self.lib.vicorc_out_nvar.restype = ctypes.c_int
+
+
+def _orc_output_list(self):
+    """{name: (index, nelem, aggregation)} of the variables the oracle (and the product) provides."""
+    _orc_out(self)
+    return {self.lib.vicorc_out_var_name(v).decode(): (v, self.lib.vicorc_out_var_nelem(self.h, v), self.lib.vicorc_out_var_agg(v))
+            for v in range(self.lib.vicorc_out_nvar())}
+
+
+def _orc_get_output(self, name, agg=False):
+    v, ne, _ = self.output_list()[name]
+    out = np.zeros((ne, self.dom.ncell))
+    f = self.lib.vicorc_get_output; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
+    assert f(self.h, v, int(agg), _d(out)) == ne
+    return out
+
+
+def _orc_set_fluxes(self, fx):
+    fx = np.ascontiguousarray(fx, dtype=np.float64)
+    f = self.lib.vicorc_set_fluxes; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, _dp]
+    assert f(self.h, _d(fx)) == 0
+
+
+OracleModel.output_list = _orc_output_list
+OracleModel.get_output = _orc_get_output
+OracleModel.set_fluxes = _orc_set_fluxes
 
 
 def have_ref(variant="plain"):

@@ -26,6 +26,7 @@
 #endif
 
 #include "vicgpu.h"
+#include "vicgpu_out.h"
 #include "GlacierMassBalanceResult.h"
 
 struct vicref_handle {
@@ -38,6 +39,8 @@ struct vicref_handle {
   std::vector<int> cell_off, cell_list;
   std::vector<double> cp;             /* copy of the cell parameter table */
   int cp_nrow;
+  std::vector<OutputData*> out;       /* the reference's own output list (create_output_list) per cell, for put_data */
+  OutputData *out_template = NULL;
 };
 
 static inline double cpv(const vicref_handle *h, int row, int c) { return h->cp[(size_t)row * h->ncell + c]; }
@@ -409,6 +412,7 @@ static void export_flux(vicref_handle *h, double *fx, double *cell_out, const in
     FXP(FX_SNOW_VAPOR_FLUX) = s.vapor_flux; FXP(FX_SNOW_CANOPY_VAPOR_FLUX) = s.canopy_vapor_flux;
     FXP(FX_SNOW_BLOWING_FLUX) = s.blowing_flux; FXP(FX_SNOW_SURFACE_FLUX) = s.surface_flux;
     FXP(FX_SNOW_MELT) = s.melt; FXP(FX_SNOW_MASS_ERROR) = s.mass_error; FXP(FX_SNOW_QNET) = s.Qnet;
+    for (int l = 0; l < 3; l++) { FXP(FX_FDEPTH0 + l) = e.fdepth[l]; FXP(FX_TDEPTH0 + l) = e.tdepth[l]; FXP(FX_ZWTL0 + l) = cw.layer[l].zwt; }
     for (int p = 0; p < 6; p++) FXP(FX_POT_EVAP0 + p) = cw.pot_evap[p];
     FXP(FX_AERO_RESIST_SURFACE) = cw.aero_resist.surface; FXP(FX_AERO_RESIST_OVERSTORY) = cw.aero_resist.overstory;
     FXP(FX_ROOTMOIST) = cw.rootmoist; FXP(FX_WETNESS) = cw.wetness;
@@ -463,6 +467,84 @@ int vicref_step(void *hv, const double *forcing, const unsigned char *snowflag, 
   }
   if (flux) export_flux(h, flux, cell_out, cell_err);
   return nerr;
+}
+
+int vicref_get_fluxes(void *hv, double *flux) { export_flux((vicref_handle *)hv, flux, NULL, NULL); return 0; }
+
+/* ---- the reference's own put_data (put_data.c:7) on the harness's cells, for pinning oracle/orc_putdata.c.
+ * rec < 0: the initialisation call of vicNl.c:524-541; otherwise the harness keeps ONE atmos record per cell, so the
+ * call is made with rec = 0 (put_data only indexes cell->atmos with it and compares it with 0 / nrecs-1 for messages).
+ * forcing / cell_out: the step's forcing and out_prec/out_rain/out_snow (vicref_step's cell_out). */
+int vicref_put_data(void *hv, int rec, const double *forcing, const double *cell_out, int out_step_ratio) {
+  vicref_handle *h = (vicref_handle *)hv;
+  h->state.out_step_ratio = out_step_ratio;
+  if (!h->out_template) h->out_template = create_output_list(&h->state);
+  if (h->out.empty()) {
+    for (int c = 0; c < h->ncell; c++) copy_output_data(h->out, h->out_template, &h->state);   /* one list per cell (vicNl.c) */
+  }
+  dmy_struct d; memset(&d, 0, sizeof(d));
+  for (int c = 0; c < h->ncell; c++) {
+    cell_info_struct &cell = h->cells[c];
+    if (rec >= 0) {
+      load_atmos(h, c, forcing, NULL);
+      cell.atmos->out_prec = cell_out[(size_t)CO_OUT_PREC * h->ncell + c];
+      cell.atmos->out_rain = cell_out[(size_t)CO_OUT_RAIN * h->ncell + c];
+      cell.atmos->out_snow = cell_out[(size_t)CO_OUT_SNOW * h->ncell + c];
+    }
+    int err = put_data(&cell, NULL, h->out[c], &d, rec < 0 ? -1 : 0, &h->state);
+    if (err == ERROR) return -1;
+  }
+  return 0;
+}
+
+/* number of variables of the reference's list; name / nelem / aggtype of variable v */
+int vicref_out_nvar(void) { return N_OUTVAR_TYPES; }
+int vicref_out_info(void *hv, int v, char *name, int *nelem, int *aggtype) {
+  vicref_handle *h = (vicref_handle *)hv;
+  if (!h->out_template) h->out_template = create_output_list(&h->state);
+  if (v < 0 || v >= N_OUTVAR_TYPES) return -1;
+  strcpy(name, h->out_template[v].varname.c_str());
+  /* three variables get no varname in output_list_utils.c (they cannot be selected in a global file); the harness names
+   * them after their enum so that the tests can address them */
+  if (v == OUT_AREA_BAND) strcpy(name, "OUT_AREA_BAND");
+  if (v == OUT_ELEV_BAND) strcpy(name, "OUT_ELEV_BAND");
+  if (v == OUT_GLAC_MELT_ENERGY) strcpy(name, "OUT_GLAC_MELT_ENERGY");
+  *nelem = h->out_template[v].nelem;
+  *aggtype = h->out_template[v].aggtype;   /* AGG_TYPE_* */
+  return 0;
+}
+/* which: 0 = data, 1 = aggdata; out [nelem][ncell]; returns nelem */
+int vicref_get_output(void *hv, int v, int which, double *out) {
+  vicref_handle *h = (vicref_handle *)hv;
+  if (h->out.empty() || v < 0 || v >= N_OUTVAR_TYPES) return -1;
+  const int ne = h->out_template[v].nelem;
+  for (int c = 0; c < h->ncell; c++)
+    for (int i = 0; i < ne; i++) out[(size_t)i * h->ncell + c] = which ? h->out[c][v].aggdata[i] : h->out[c][v].data[i];
+  return ne;
+}
+int vicref_reset_agg(void *hv) {       /* vicNl.c:599-606 */
+  vicref_handle *h = (vicref_handle *)hv;
+  for (size_t c = 0; c < h->out.size(); c++)
+    for (int v = 0; v < N_OUTVAR_TYPES; v++)
+      for (int i = 0; i < h->out_template[v].nelem; i++) h->out[c][v].aggdata[i] = 0;
+  return 0;
+}
+/* save_data, cellErrors and fallBackStats of every cell: [PB_NROW][ncell] (include/vicgpu_out.h) */
+int vicref_get_balance(void *hv, double *pb) {
+  vicref_handle *h = (vicref_handle *)hv;
+  const size_t nc = h->ncell;
+  for (int c = 0; c < h->ncell; c++) {
+    const cell_info_struct &cell = h->cells[c];
+    pb[PB_SAVE_TOTAL_SOIL_MOIST * nc + c] = cell.save_data.total_soil_moist; pb[PB_SAVE_SWE * nc + c] = cell.save_data.swe;
+    pb[PB_SAVE_WDEW * nc + c] = cell.save_data.wdew; pb[PB_SAVE_SURFSTOR * nc + c] = cell.save_data.surfstor;
+    pb[PB_WATER_LAST_STORAGE * nc + c] = cell.cellErrors.water_last_storage; pb[PB_WATER_CUM_ERROR * nc + c] = cell.cellErrors.water_cum_error;
+    pb[PB_WATER_MAX_ERROR * nc + c] = cell.cellErrors.water_max_error; pb[PB_ENERGY_CUM_ERROR * nc + c] = cell.cellErrors.energy_cum_error;
+    pb[PB_ENERGY_MAX_ERROR * nc + c] = cell.cellErrors.energy_max_error;
+    pb[PB_FB_TFOLIAGE * nc + c] = cell.fallBackStats.Tfoliage_fbcount_total; pb[PB_FB_TCANOPY * nc + c] = cell.fallBackStats.Tcanopy_fbcount_total;
+    pb[PB_FB_TSNOWSURF * nc + c] = cell.fallBackStats.Tsnowsurf_fbcount_total; pb[PB_FB_TSURF * nc + c] = cell.fallBackStats.Tsurf_fbcount_total;
+    pb[PB_FB_TSOIL * nc + c] = cell.fallBackStats.Tsoil_fbcount_total; pb[PB_FB_TGLACSURF * nc + c] = cell.fallBackStats.Tglacsurf_fbcount_total;
+  }
+  return 0;
 }
 
 /* Timed multi-step run for bench.py's cpu_baseline leg: forcing [nsteps][VIC_NFORCE][NF+1][ncell].

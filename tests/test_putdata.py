@@ -1,0 +1,194 @@
+"""put_data (put_data.c:7-1232, calc_water_energy_balance_errors.c): the oracle's restatement (oracle/orc_putdata.c)
+against the reference's own put_data, called through the shim on the reference's own HRU structs -- every variable of
+include/vicgpu_out.h, un-aggregated and aggregated, the per-cell bookkeeping (save_data, cellErrors, fallBackStats), bit
+for bit; and the variable table itself (names, element counts, aggregation types) against create_output_list."""
+import numpy as np
+import pytest
+
+from vic_amd import abi, domain
+from vic_amd.abi import C
+from tests.util import rel_diff, worst
+
+FROZEN = dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=0)
+CASES = [
+    ("quickflux_bands", dict(FULL_ENERGY=1, Nband=3), "plain", 6, 3, False, 120, 70, 1),
+    ("wb_daily", dict(FULL_ENERGY=0, dt=24, snow_step=3), "plain", 6, 3, False, 60, 330, 1),
+    ("frozen_bands_agg24", dict(FROZEN, Nband=2), "fixed", 4, 3, False, 96, 80, 24),
+    ("glacier_agg6", dict(FULL_ENERGY=1, Nband=3), "plain", 6, 2, True, 96, 150, 6),
+    ("glacier_frozen", dict(FROZEN, Nband=2), "fixed", 4, 2, True, 72, 110, 3),
+    ("stress_fallback", dict(FULL_ENERGY=1, TFALLBACK=1), "plain", 6, 3, False, 48, 70, 4),
+]
+AGG = {0: "AGG_TYPE_AVG", 1: "AGG_TYPE_BEG", 2: "AGG_TYPE_END", 3: "AGG_TYPE_MAX", 4: "AGG_TYPE_MIN", 5: "AGG_TYPE_SUM"}   # vicNl_def.h
+
+
+def test_variable_table_matches_the_reference(oracle_lib, ref_available):
+    """Every variable the library provides exists in the reference's list under the same name, with the same number of
+    elements and the same aggregation; what the library leaves out is lake / excess-ice / cloud-cover only."""
+    if not ref_available:
+        pytest.skip("reference build (oracle/_ref) not available")
+    opt = abi.default_options(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=4)
+    d = domain.make_domain(2, opt, ntile=1)
+    ref = oracle_lib.RefModel(d, "fixed")
+    orc = oracle_lib.OracleModel(d)
+    rl, ol = ref.output_list(), orc.output_list()
+    agg_map = {C["VOUT_AGG_END"]: "AGG_TYPE_END", C["VOUT_AGG_SUM"]: "AGG_TYPE_SUM", C["VOUT_AGG_AVG"]: "AGG_TYPE_AVG"}
+    for name, (v, ne, ag) in ol.items():
+        assert name in rl, name
+        assert rl[name][1] == ne, (name, rl[name][1], ne)
+        assert AGG[rl[name][2]] == agg_map[ag], (name, AGG[rl[name][2]], agg_map[ag])
+    missing = sorted(set(rl) - set(ol))
+    allowed = ("OUT_LAKE_", "OUT_SOIL_TNODE_WL", "OUT_TSKC", "OUT_SOIL_DEPTH", "OUT_SUBSIDENCE", "OUT_POROSITY", "OUT_ZSUM_NODE")
+    assert all(m.startswith(allowed) for m in missing), [m for m in missing if not m.startswith(allowed)]
+    ref.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_oracle_put_data_vs_reference(case, oracle_lib, ref_available):
+    if not ref_available:
+        pytest.skip("reference build (oracle/_ref) not available")
+    name, kw, variant, ncell, ntile, glacier, nsteps, doy, ratio = case
+    opt = abi.default_options(**kw)
+    d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
+    if name == "stress_fallback":
+        f[5::7, C["VIC_F_SHORTWAVE"]][..., np.arange(d.ncell) % 3 == 1] = 60000.0
+    ref = oracle_lib.RefModel(d, variant)
+    ref.init_state(f[0], dmy[0], d.init_moist)
+    sd0, si0 = ref.get_state()
+    if glacier:
+        sd0[C["SD_GLAC_CUM_MASS_BALANCE"], d.hru_iparams[C["HPI_IS_GLACIER"]] != 0] = 0.0
+        ref.set_state(sd0, si0)
+    orc = oracle_lib.OracleModel(d)
+    orc.set_state(sd0, si0)
+    orc.set_fluxes(ref.get_fluxes())            # what initialize_model_state leaves in the HRUs besides the state tables
+    names = list(orc.output_list())
+    ref.put_data(-1); orc.put_data(-1)          # vicNl.c:524-541
+    # the reference never initialises OutputData.aggdata (output_list_utils.c:482 `new double[nelem]`, first cleared after the
+    # first write, vicNl.c:599-606): start both sides from zero
+    ref.reset_agg(); orc.reset_agg()
+    assert np.array_equal(ref.get_balance(), orc.get_balance())
+    step_in_interval = 0
+    for s in range(nsteps):
+        fr, cr, er = ref.step(f[s], sf[s], dmy[s])
+        fo, co, eo = orc.step(f[s], sf[s], dmy[s])
+        assert er.sum() == 0 and eo.sum() == 0
+        ref.put_data(s, f[s], cr, ratio); orc.put_data(s, f[s], co, ratio)
+        step_in_interval += 1
+        for n in names:
+            for agg in (False, True):
+                a, b = ref.get_output(n, agg), orc.get_output(n, agg)
+                assert np.array_equal(a, b, equal_nan=True), "step %d %s %s: worst %.3e (%r vs %r)" % (
+                    s, n, "aggdata" if agg else "data", rel_diff(a, b, 1e-300).max(), a.ravel()[:3], b.ravel()[:3])
+        assert np.array_equal(ref.get_balance(), orc.get_balance(), equal_nan=True), "step %d bookkeeping" % s
+        if step_in_interval == ratio:           # vicNl.c:596-608
+            ref.reset_agg(); orc.reset_agg()
+            step_in_interval = 0
+    pb = orc.get_balance()
+    assert np.abs(pb[C["PB_WATER_CUM_ERROR"]]).max() < 1e-6            # the model closes its water balance
+    if name == "stress_fallback":
+        assert pb[C["PB_FB_TSURF"]].max() > 0
+    ref.close()
+
+
+# ------------------------------------------------------------------------------------------------ the device's put_data
+GPU_CASES = [
+    # name, options, ncell, ntile, glacier, nsteps, start_doy, out_step_ratio, node solver
+    ("quickflux_bands", dict(FULL_ENERGY=1, Nband=3), 70, 3, False, 48, 70, 6, "brent"),
+    ("wb_daily", dict(FULL_ENERGY=0, dt=24, snow_step=3), 70, 3, False, 30, 330, 1, "brent"),
+    ("frozen_bands", dict(FROZEN, Nband=2), 12, 3, False, 36, 80, 12, "brent"),
+    ("frozen_bands_newton", dict(FROZEN, Nband=2), 12, 3, False, 36, 80, 12, "newton"),
+    ("glacier_agg6", dict(FULL_ENERGY=1, Nband=3), 70, 2, True, 36, 150, 6, "brent"),
+    ("glacier_frozen", dict(FROZEN, Nband=2), 12, 2, True, 36, 110, 3, "brent"),
+]
+# differences of nearly equal storages and balance residuals: compared absolutely (mm, W/m2)
+DIFF_VARS = ("OUT_DELSOILMOIST", "OUT_DELSWE", "OUT_DELINTERCEPT", "OUT_DELSURFSTOR", "OUT_WATER_ERROR", "OUT_ENERGY_ERROR")
+PUT_TOL = 1e-6
+
+
+def _compare_outputs(names, nelem, og, oo, where):
+    row = 0
+    for n, ne in zip(names, nelem):
+        a, b = oo[row:row + ne], og[row:row + ne]
+        row += ne
+        if n in DIFF_VARS:
+            with np.errstate(invalid="ignore"):
+                w = np.nanmax(np.abs(a - b)) if a.size else 0.0
+            assert not (w > 1e-6) and np.array_equal(np.isnan(a), np.isnan(b)), "%s %s: |diff| %.3e" % (where, n, w)
+        else:
+            w = rel_diff(a, b, 1e-6).max()
+            assert w < PUT_TOL, "%s %s: worst rel diff %.3e" % (where, n, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_CASES, ids=[c[0] for c in GPU_CASES])
+def test_device_put_data_against_oracle(case, oracle_lib):
+    """vic_put_data against the oracle's put_data (itself bit-exact against the reference's, above).  The initialisation
+    call sees the same state and flux tables on both sides, so it must agree to the last bit (except OUT_RAD_TEMP, which
+    goes through pow); after that the device's own step results feed its put_data, so the per-step values, the
+    aggregates over the output interval (as doubles and as the floats handed to the writer) and the balance bookkeeping
+    carry the step's own 1e-6 bound.  The flux table starts from arbitrary values: what a step does not rewrite (frost
+    fronts of glacier HRUs) must survive it on both sides."""
+    from vic_amd import init_state
+    from vic_amd.api import Model
+    name, kw, ncell, ntile, glacier, nsteps, doy, ratio, solver = case
+    opt = abi.default_options(**dict(kw, NODE_SOLVER=C["VIC_NODE_SOLVER_NEWTON" if solver == "newton" else "VIC_NODE_SOLVER_BRENT"]))
+    d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
+    sd0, si0 = init_state.initial_state(d, f[0])
+    if glacier:
+        sd0[C["SD_GLAC_CUM_MASS_BALANCE"], d.hru_iparams[C["HPI_IS_GLACIER"]] != 0] = 0.0
+    fx0 = np.random.default_rng(5).uniform(0.05, 2.0, size=(C["FX_NROW"], d.nhru))
+    orc = oracle_lib.OracleModel(d, converged_nodes=(solver == "newton"))
+    orc.set_state(sd0, si0)
+    orc.set_fluxes(fx0)
+    gpu = Model(d)
+    gpu.set_state(sd0, si0)
+    gpu.set_fluxes(fx0)
+    gpu.push_forcing(f, sf, dmy)
+    gpu.put_data_config(ratio)
+    table = gpu.output_list()
+    assert [t[0] for t in table] == list(orc.output_list())
+    names, nelem = [t[0] for t in table], [t[1] for t in table]
+    orc.put_data(-1); gpu.put_data_init()
+    oo = np.concatenate([orc.get_output(n, False) for n in names])
+    og = gpu.get_output_data(names)
+    r0 = int(np.sum(nelem[:names.index("OUT_RAD_TEMP")]))
+    assert rel_diff(oo[r0], og[r0], 1e-300).max() < 1e-14
+    oo[r0] = og[r0]
+    assert np.array_equal(oo, og, equal_nan=True), "initialisation call: %d values differ" % (oo != og).sum()
+    assert np.array_equal(orc.get_balance(), gpu.get_balance())
+    orc.reset_agg()
+    k = 0
+    for s in range(nsteps):
+        sd_in, si_in = orc.get_state()
+        fo, co, eo = orc.step(f[s], sf[s], dmy[s])
+        orc.put_data(s, f[s], co, ratio)
+        gpu.set_state(sd_in, si_in)
+        gpu.dist_prec(s, 1)
+        assert eo.sum() == 0 and gpu.get_cell_errors().sum() == 0
+        so, sg = orc.get_state()[0], gpu.get_state()[0]
+        so[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
+        w, msg = worst(so, sg, "SD_", floor=1e-6)
+        assert w < PUT_TOL, "step %d state %s" % (s, msg)
+        oo = np.concatenate([orc.get_output(n, False) for n in names])
+        _compare_outputs(names, nelem, gpu.get_output_data(names), oo, "step %d data" % s)
+        oa = np.concatenate([orc.get_output(n, True) for n in names])
+        ga = gpu.get_output_data(names, aggregated=True)
+        _compare_outputs(names, nelem, ga, oa, "step %d aggdata" % s)
+        k += 1
+        if k == ratio:                              # the writer takes the aggregates as floats, then they are cleared
+            sel = ["OUT_RUNOFF", "OUT_BASEFLOW", "OUT_SWE", "OUT_SOIL_MOIST", "OUT_EVAP", "OUT_SWE_BAND", "OUT_GLAC_MBAL"]
+            gf = gpu.get_outputs(sel, reset=True)
+            want = gpu.var_ids(sel)
+            rows = np.concatenate([np.arange(int(np.sum(nelem[:v])), int(np.sum(nelem[:v])) + nelem[v]) for v in want])
+            assert gf.dtype == np.float32 and np.array_equal(gf, ga[rows].astype(np.float32), equal_nan=True)
+            assert not gpu.get_output_data(names, aggregated=True).any()
+            orc.reset_agg()
+            k = 0
+    pg, po = gpu.get_balance(), orc.get_balance()
+    fb = [C[r] for r in ("PB_FB_TFOLIAGE", "PB_FB_TCANOPY", "PB_FB_TSNOWSURF", "PB_FB_TSURF", "PB_FB_TSOIL", "PB_FB_TGLACSURF")]
+    assert np.array_equal(pg[fb], po[fb])
+    assert np.abs(pg[C["PB_WATER_CUM_ERROR"]]).max() < 1e-6
+    assert np.abs(pg[C["PB_WATER_CUM_ERROR"]] - po[C["PB_WATER_CUM_ERROR"]]).max() < 1e-6
+    st = [C[r] for r in ("PB_SAVE_TOTAL_SOIL_MOIST", "PB_SAVE_SWE", "PB_SAVE_WDEW", "PB_WATER_LAST_STORAGE")]
+    assert rel_diff(pg[st], po[st], 1e-6).max() < PUT_TOL

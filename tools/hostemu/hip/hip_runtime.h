@@ -73,7 +73,7 @@ struct Wave {
   unsigned long long present = 0, snap_mask = 0;
   uint64_t slot[64], snap[64];
   const std::function<void()>* body = nullptr;
-  unsigned block = 0, first_thread = 0;
+  unsigned block = 0, block_y = 0, first_thread = 0;
   const void* sched_bottom = nullptr;
   size_t sched_size = 0;
 
@@ -120,7 +120,7 @@ struct Wave {
       for (int l = 0; l < nlane; l++) {
         if (done[l]) continue;
         cur = l;
-        threadIdx = dim3(first_thread + (unsigned)l); blockIdx = dim3(block);
+        threadIdx = dim3(first_thread + (unsigned)l); blockIdx = dim3(block, block_y);
         hostemu_set_lane(this, l);
 #ifdef HOSTEMU_ASAN
         void* fs = nullptr;
@@ -174,12 +174,13 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   gridDim = grid; blockDim = block;
   const int nthread = (int)block.x, nwave = (nthread + 63) / 64;
   static thread_local Wave* w = new Wave;
-  for (unsigned b = 0; b < grid.x; b++)
-    for (int i = 0; i < nwave; i++) {
-      w->nlane = std::min(64, nthread - 64 * i);
-      w->body = &body; w->block = b; w->first_thread = 64u * i; w->present = 0;
-      w->run();
-    }
+  for (unsigned by = 0; by < grid.y; by++)
+    for (unsigned b = 0; b < grid.x; b++)
+      for (int i = 0; i < nwave; i++) {
+        w->nlane = std::min(64, nthread - 64 * i);
+        w->body = &body; w->block = b; w->block_y = by; w->first_thread = 64u * i; w->present = 0;
+        w->run();
+      }
 }
 
 inline void* device_alloc(size_t n) {
@@ -224,6 +225,10 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { m
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemset2DAsync(void* d, size_t pitch, int v, size_t width, size_t height, hipStream_t = nullptr) {
+  for (size_t r = 0; r < height; r++) memset((char*)d + r * pitch, v, width);
+  return hipSuccess;
+}
 inline hipError_t hipMemcpyFromSymbol(void* d, const void* sym, size_t n) { memcpy(d, sym, n); return hipSuccess; }
 inline hipError_t hipMemcpyToSymbol(void* sym, const void* s, size_t n) { memcpy(sym, s, n); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }

@@ -21,6 +21,8 @@ def _parse_header(path):
     for m in re.finditer(r"^#define\s+([A-Z_0-9a-z]+)\s+(-?\d+)\s*$", txt, flags=re.M):
         consts[m.group(1)] = int(m.group(2))
     for m in re.finditer(r"enum\s*\{(.*?)\}\s*;", txt, flags=re.S):
+        if "(" in m.group(1) and "VICGPU_OUT_VARS" in m.group(1):
+            continue                                  # generated from the X-macro list
         val = -1
         for item in m.group(1).split(","):
             item = item.strip()
@@ -37,6 +39,8 @@ def _parse_header(path):
 
 
 C = _parse_header(HEADER)
+# put_data's tables (include/vicgpu_out.h): the plain enums; the variable list itself is an X-macro, read from the library
+C.update(_parse_header(os.path.join(os.path.dirname(HEADER), "vicgpu_out.h")))
 globals().update(C)
 
 VIC_NLAYER = C["VIC_NLAYER"]

@@ -61,6 +61,19 @@ def load_library():
         "vicgpu_last_kernel_ms": (ctypes.c_int, [vp, _dp, _ip]),
         "vicgpu_debug_pure": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
         "vicgpu_glacier_mass_balance_fit": (ctypes.c_int, [vp, _dp, ctypes.c_int]),
+        # include/vicgpu_out.h
+        "vicgpu_out_nvar": (ctypes.c_int, []),
+        "vicgpu_out_var_id": (ctypes.c_int, [ctypes.c_char_p]),
+        "vicgpu_out_var_name": (ctypes.c_char_p, [ctypes.c_int]),
+        "vicgpu_out_var_kind": (ctypes.c_int, [ctypes.c_int]),
+        "vicgpu_out_var_agg": (ctypes.c_int, [ctypes.c_int]),
+        "vicgpu_out_var_nelem": (ctypes.c_int, [ctypes.POINTER(abi.Options), ctypes.c_int]),
+        "vicgpu_put_data_config": (ctypes.c_int, [vp, ctypes.c_int]),
+        "vicgpu_put_data_init": (ctypes.c_int, [vp]),
+        "vicgpu_get_outputs": (ctypes.c_int, [vp, ctypes.c_int, _ip, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
+        "vicgpu_get_output_data": (ctypes.c_int, [vp, ctypes.c_int, _ip, ctypes.c_int, _dp]),
+        "vicgpu_get_balance": (ctypes.c_int, [vp, _dp]),
+        "vicgpu_set_fluxes": (ctypes.c_int, [vp, _dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)   # AttributeError here = the library does not export a declared symbol
@@ -78,6 +91,9 @@ EXPORTED_SYMBOLS = [
     "vicgpu_get_cell_outputs", "vicgpu_get_accum", "vicgpu_reset_accum", "vicgpu_get_cell_errors", "vicgpu_set_stream",
     "vicgpu_set_write_fluxes", "vicgpu_device_ptr", "vicgpu_last_kernel_ms", "vicgpu_debug_pure",
     "vicgpu_glacier_mass_balance_fit",
+    "vicgpu_out_nvar", "vicgpu_out_var_id", "vicgpu_out_var_name", "vicgpu_out_var_kind", "vicgpu_out_var_agg", "vicgpu_out_var_nelem",
+    "vicgpu_put_data_config", "vicgpu_put_data_init", "vicgpu_get_outputs", "vicgpu_get_output_data", "vicgpu_get_balance",
+    "vicgpu_set_fluxes",
 ]
 
 
@@ -183,6 +199,51 @@ class Model:
 
     def set_write_fluxes(self, on):
         self._chk(self.lib.vicgpu_set_write_fluxes(self.h, int(bool(on))))
+
+    # ---- put_data: the aggregated output variables (include/vicgpu_out.h)
+    def output_list(self):
+        """[(name, nelem, aggregation)] of every variable the library provides, index = variable id."""
+        lib = self.lib
+        return [(lib.vicgpu_out_var_name(v).decode(), lib.vicgpu_out_var_nelem(ctypes.byref(self.opt), v), lib.vicgpu_out_var_agg(v))
+                for v in range(lib.vicgpu_out_nvar())]
+
+    def var_ids(self, names):
+        ids = [self.lib.vicgpu_out_var_id(n.encode()) for n in names]
+        if min(ids) < 0:
+            raise VicGpuError("output variable not provided: %s" % [n for n, i in zip(names, ids) if i < 0])
+        return np.asarray(ids, dtype=np.int32)
+
+    def put_data_config(self, out_step_ratio=1):
+        self._chk(self.lib.vicgpu_put_data_config(self.h, int(out_step_ratio)))
+
+    def put_data_init(self):
+        self._chk(self.lib.vicgpu_put_data_init(self.h))
+
+    def _out_rows(self, ids):
+        return int(sum(self.lib.vicgpu_out_var_nelem(ctypes.byref(self.opt), int(v)) for v in ids))
+
+    def get_outputs(self, names, reset=True):
+        """The aggregates (OutputData.aggdata) of the named variables as the writer wants them: float32 [sum nelem][ncell]."""
+        ids = self.var_ids(names)
+        out = np.zeros((self._out_rows(ids), self.dom.ncell), dtype=np.float32)
+        self._chk(self.lib.vicgpu_get_outputs(self.h, len(ids), _i(ids), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(bool(reset))))
+        return out
+
+    def get_output_data(self, names, aggregated=False):
+        ids = self.var_ids(names)
+        out = np.zeros((self._out_rows(ids), self.dom.ncell))
+        self._chk(self.lib.vicgpu_get_output_data(self.h, len(ids), _i(ids), int(bool(aggregated)), _d(out)))
+        return out
+
+    def get_balance(self):
+        pb = np.zeros((C["PB_NROW"], self.dom.ncell))
+        self._chk(self.lib.vicgpu_get_balance(self.h, _d(pb)))
+        return pb
+
+    def set_fluxes(self, fx):
+        fx = np.ascontiguousarray(fx, dtype=np.float64)
+        assert fx.shape == (C["FX_NROW"], self.dom.nhru)
+        self._chk(self.lib.vicgpu_set_fluxes(self.h, _d(fx)))
 
     def glacier_mass_balance_fit(self, reset=True):
         """End of a glacier accumulation interval (accumulateGlacierMassBalance.c:53-66): [GMB_NROW][ncell] fit per cell."""

@@ -188,7 +188,7 @@ VIC_DEV double compute_zwt(const CellView& cv, int l, double moist) {
   return zwt;
 }
 
-struct Zwt { double zwt, zwt2, zwt3; };
+struct Zwt { double zwt, zwt2, zwt3, lz[3]; };   // lz: layer[l].zwt
 // wrap_compute_zwt (compute_zwt.c:49-112)
 VIC_DEV Zwt wrap_compute_zwt(const CellView& cv, const Soil3& s3, const double* moist) {
   Zwt r;
@@ -218,6 +218,8 @@ VIC_DEV Zwt wrap_compute_zwt(const CellView& cv, const Soil3& s3, const double* 
   for (int k = 0; k < 3; k++) tm += moist[k];
   r.zwt3 = compute_zwt(cv, 4, tm);
   if (isnan(r.zwt3)) r.zwt3 = -total_depth * 100;
+#pragma unroll
+  for (int k = 0; k < 3; k++) r.lz[k] = lz[k];
   return r;
 }
 

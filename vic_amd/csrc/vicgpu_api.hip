@@ -10,6 +10,7 @@
 //                      Brent step on Tsurf } -> stage kernel.  See vic_profile.hpp for why.
 //   vic_cell_reduce    one lane per cell: atmos->out_prec/out_rain/out_snow (full_energy.c:429-431) summed in hruList
 //                      order (deterministic, no atomics) and the Cv-weighted per-cell accumulators.
+//   vic_put_sum/_finish/_aggregate   put_data (put_data.c:7-760), the aggregated output variables (vic_putdata.hpp)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,6 +26,7 @@
 #include <type_traits>
 #include "vic_glacier.hpp"
 #include "vic_profile.hpp"
+#include "vic_putdata.hpp"
 
 using namespace vic;
 
@@ -315,7 +317,7 @@ VIC_DEV void store_state(const KArgs& a, int g, const HruWork<NN>& w) {
 }
 
 template <int NN>
-VIC_DEV void store_flux(const KArgs& a, int g, const HruWork<NN>& w) {
+VIC_DEV void store_flux(const KArgs& a, int g, const HruWork<NN>& w, bool glac) {
   const size_t nh = a.nhru;
   double* __restrict__ fx = a.flux;
 #define FX(row) fx[(size_t)(row) * nh + g]
@@ -334,6 +336,14 @@ VIC_DEV void store_flux(const KArgs& a, int g, const HruWork<NN>& w) {
   FX(FX_AERO_RESIST_SURFACE) = w.aero_resist_surface; FX(FX_AERO_RESIST_OVERSTORY) = w.aero_resist_overstory;
   FX(FX_ROOTMOIST) = w.rootmoist; FX(FX_WETNESS) = w.wetness;
   FX(FX_ZWT) = w.zwt.zwt; FX(FX_ZWT2) = w.zwt.zwt2; FX(FX_ZWT3) = w.zwt.zwt3;
+#pragma unroll
+  for (int l = 0; l < 3; l++) FX(FX_ZWTL0 + l) = w.zwt.lz[l];
+  // the frost / thaw fronts exist where find_0_degree_fronts ran (surface_fluxes.c, FROZEN_SOIL); glacier HRUs keep the
+  // values initialize_model_state gave them (vicgpu_set_fluxes), as they do in the reference
+  if (a.o.FROZEN_SOIL && !glac) {
+#pragma unroll
+    for (int l = 0; l < 3; l++) { FX(FX_FDEPTH0 + l) = w.so.fdepth[l]; FX(FX_TDEPTH0 + l) = w.so.tdepth[l]; }
+  }
   FX(FX_ATMOS_LATENT) = w.AtmosLatent; FX(FX_ATMOS_LATENT_SUB) = w.AtmosLatentSub; FX(FX_ATMOS_SENSIBLE) = w.AtmosSensible;
   FX(FX_LONG_UNDER_IN) = w.LongUnderIn; FX(FX_NET_LONG_ATMOS) = w.NetLongAtmos; FX(FX_NET_LONG_UNDER) = w.so.NetLongUnder;
   FX(FX_NET_SHORT_ATMOS) = w.NetShortAtmos; FX(FX_NET_SHORT_GRND) = w.so.NetShortGrnd; FX(FX_NET_SHORT_UNDER) = w.so.NetShortUnder;
@@ -470,7 +480,7 @@ VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView&
 
 // full_energy.c:437-455 and state / flux out
 template <int NN>
-VIC_DEV void hru_epilogue(const KArgs& a, int g, const CellView& cv, const Soil3& s3, const StepConst& C, HruWork<NN>& w, int err) {
+VIC_DEV void hru_epilogue(const KArgs& a, int g, const CellView& cv, const Soil3& s3, const StepConst& C, HruWork<NN>& w, int err, bool glac) {
   // root zone moisture and wetness (full_energy.c:437-455)
   w.rootmoist = 0; w.wetness = 0;
 #pragma unroll
@@ -488,7 +498,7 @@ VIC_DEV void hru_epilogue(const KArgs& a, int g, const CellView& cv, const Soil3
 
   PROF_T0(t_store);
   store_state<NN>(a, g, w);
-  store_flux<NN>(a, g, w);
+  store_flux<NN>(a, g, w, glac);
   a.hru_err[g] = err;
   PROF_ADD(8, t_store);
 }
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
     }
     if (!ok) err |= VICGPU_CELLERR_SOLVER;
   }
-  hru_epilogue<NN>(a, g, cv, s3, C, w, err);
+  hru_epilogue<NN>(a, g, cv, s3, C, w, err, GLAC);
   PROF_ADD(0, t_kernel);
   PROF_WAVE(0);
   PROF_LANE(1);
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
     PROF_T0(t_end);
     if (more && !sf_end<NN>(o, cv, s3, C, w, L)) err |= VICGPU_CELLERR_SOLVER;
     PROF_ADD(15, t_end);
-    hru_epilogue<NN>(a, g, cv, s3, C, w, err);
+    hru_epilogue<NN>(a, g, cv, s3, C, w, err, false);
     a.hstate[g] = 0;
   }
   list_append(a.list, a.count, a.list_cap, pend, key, g);
@@ -983,12 +993,22 @@ struct vicgpu_ctx {
   bool node_newton = false;        // frozen-node root finder: safeguarded Newton instead of the reference's Brent iteration
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
+  // put_data (vicgpu_out.h): output tables [nrow][ncell], allocated by vicgpu_put_data_config
+  bool put_on = false;
+  int out_step_ratio = 1, out_nrow = 0;
+  OutLayout out_lay;
+  double *d_out_data = nullptr, *d_out_agg = nullptr, *d_pb = nullptr;
+  unsigned char* d_rowagg = nullptr;   // [out_nrow] aggregation type of every output row
 };
 
 static void free_domain(vicgpu_ctx* c) {
   void* ps[] = {c->d_cp, c->d_hpd, c->d_sd, c->d_flux, c->d_cell_out, c->d_accum, c->d_hpi, c->d_si, c->d_cell_off, c->d_cell_list,
-                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_pslot, c->d_hkey};
+                c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_pslot, c->d_hkey,
+                c->d_out_data, c->d_out_agg, c->d_pb, c->d_rowagg};
   for (void* p : ps) HIPIGN(hipFree(p));
+  c->d_out_data = c->d_out_agg = c->d_pb = nullptr;
+  c->d_rowagg = nullptr;
+  c->put_on = false;
   for (FdChunk& ch : c->chunks) {
     HIPIGN(hipFree(ch.d_glist)); HIPIGN(hipFree(ch.d_list[0])); HIPIGN(hipFree(ch.d_list[1])); HIPIGN(hipFree(ch.d_count));
     if (ch.h_count) HIPIGN(hipHostFree(ch.h_count));
@@ -1146,6 +1166,26 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   return VICGPU_OK;
 }
 
+// put_data for cells [c0, c0 + ccount) after step s of the forcing chunk (s < 0: the initialisation call)
+static hipError_t launch_put_data(const vicgpu_ctx* c, hipStream_t st, int c0, int ccount, int s) {
+  OArgs a;
+  a.o = c->o; a.lay = c->out_lay; a.ncell = c->ncell; a.nhru = c->nhru; a.c0 = c0; a.ccount = ccount;
+  a.rec = s < 0 ? -1 : 0; a.out_step_ratio = c->out_step_ratio;
+  a.cell_off = c->d_cell_off; a.cell_list = c->d_cell_list; a.cell_params = c->d_cp; a.veglib = c->d_veglib;
+  a.hpi = c->d_hpi; a.hpd = c->d_hpd; a.sd = c->d_sd; a.si = c->d_si; a.flux = c->d_flux;
+  a.forcing = s < 0 ? nullptr : c->d_forcing + (size_t)s * VIC_NFORCE * (c->o.NR + 1) * c->ncell;
+  a.cell_out = c->d_cell_out; a.out_data = c->d_out_data; a.out_agg = c->d_out_agg; a.pb = c->d_pb;
+  const unsigned nblk = (unsigned)((ccount + 63) / 64);
+  // zero_output_list: the columns of these cells in every row
+  hipError_t e = hipMemset2DAsync(c->d_out_data + c0, sizeof(double) * c->ncell, 0, sizeof(double) * ccount, c->out_nrow, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(vic_put_sum, dim3(nblk, PUT_NPART), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(vic_put_finish, dim3(nblk), dim3(64), 0, st, a);
+  if (s >= 0)
+    hipLaunchKernelGGL(vic_put_aggregate, dim3(nblk, (c->out_nrow + PUT_AGG_ROWS - 1) / PUT_AGG_ROWS), dim3(64), 0, st, a, c->d_rowagg);
+  return hipGetLastError();
+}
+
 struct StepPlan {
   vicgpu_ctx* c;
   KArgs ka;
@@ -1185,6 +1225,7 @@ static int fd_chunk_run(const StepPlan& plan, FdChunk* ch) {
     }
     hipLaunchKernelGGL(vic_cell_reduce, dim3((ch->ccount + 255) / 256), dim3(256), 0, ch->stream, ca);
     CHKCH(ch, hipGetLastError());
+    if (c->put_on) CHKCH(ch, launch_put_data(c, ch->stream, ch->c0, ch->ccount, s));
   }
   CHKCH(ch, hipEventRecord(ch->done, ch->stream));
   return VICGPU_OK;
@@ -1463,7 +1504,8 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   StepPlan plan;
   plan.c = c; plan.step0 = step0; plan.nsteps = nsteps;
   KArgs& ka = plan.ka;
-  ka.o = c->o; ka.ncell = c->ncell; ka.nhru = c->nhru; ka.nveg_rows = c->nveg_rows; ka.write_fluxes = c->write_fluxes;
+  ka.o = c->o; ka.ncell = c->ncell; ka.nhru = c->nhru; ka.nveg_rows = c->nveg_rows;
+  ka.write_fluxes = (c->write_fluxes || c->put_on) ? 1 : 0;      // put_data reads every row of the flux table
   ka.veglib = c->d_veglib; ka.cell_params = c->d_cp; ka.hpi = c->d_hpi; ka.hpd = c->d_hpd;
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
   ka.glist = nullptr; ka.gcount = c->nhru;
@@ -1484,6 +1526,7 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
       HIPCHK(c, hipEventRecord(c->ev[2 * (s - step0) + 1], c->stream));
       hipLaunchKernelGGL(vic_cell_reduce, dim3((c->ncell + 255) / 256), dim3(256), 0, c->stream, ca);
       HIPCHK(c, hipGetLastError());
+      if (c->put_on) HIPCHK(c, launch_put_data(c, c->stream, 0, c->ncell, s));
       c->steps_done++;
     }
     c->ev_used = nsteps;
@@ -1630,6 +1673,136 @@ void* vicgpu_device_ptr(vicgpu_ctx* c, int which) {
     case VICGPU_PTR_CELL_OUT: return c->d_cell_out;
     default: return nullptr;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ put_data (vicgpu_out.h)
+int vicgpu_out_nvar(void) { return VOUT_NVAR; }
+const char* vicgpu_out_var_name(int id) { return (id >= 0 && id < VOUT_NVAR) ? vout_name_host[id] : nullptr; }
+int vicgpu_out_var_id(const char* name) {
+  if (!name) return -1;
+  for (int v = 0; v < VOUT_NVAR; v++)
+    if (strcmp(name, vout_name_host[v]) == 0) return v;
+  return -1;
+}
+int vicgpu_out_var_kind(int id) { return (id >= 0 && id < VOUT_NVAR) ? vout_kind_host[id] : -1; }
+int vicgpu_out_var_agg(int id) { return (id >= 0 && id < VOUT_NVAR) ? vout_agg_host[id] : -1; }
+int vicgpu_out_var_nelem(const vicgpu_options* opt, int id) {
+  if (!opt || id < 0 || id >= VOUT_NVAR) return -1;
+  return vout_kind_nelem(vout_kind_host[id], opt->Nnode, opt->Nband, opt->FROZEN_SOIL);
+}
+
+int vicgpu_put_data_config(vicgpu_ctx* c, int out_step_ratio) {
+  if (!c || out_step_ratio < 1) return VICGPU_ERR_ARG;
+  if (!c->domain_ready) return VICGPU_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int r = 0;
+  for (int v = 0; v < VOUT_NVAR; v++) {
+    c->out_lay.off[v] = r; c->out_lay.agg[v] = vout_agg_host[v];
+    r += vout_kind_nelem(vout_kind_host[v], c->opt.Nnode, c->opt.Nband, c->opt.FROZEN_SOIL);
+  }
+  c->out_lay.off[VOUT_NVAR] = r;
+  c->out_nrow = r;
+  c->out_step_ratio = out_step_ratio;
+  std::vector<unsigned char> rowagg(r);
+  for (int v = 0; v < VOUT_NVAR; v++) {
+    const bool by_finish = (v == VOUT_AERO_RESIST || v == VOUT_AERO_RESIST1 || v == VOUT_AERO_RESIST2);   // vic_put_finish
+    for (int k = c->out_lay.off[v]; k < c->out_lay.off[v + 1]; k++) rowagg[k] = (unsigned char)(by_finish ? VOUT_AGG_SKIP : vout_agg_host[v]);
+  }
+  if (!c->d_out_data) {
+    HIPCHK(c, hipMalloc(&c->d_out_data, sizeof(double) * (size_t)r * c->ncell));
+    HIPCHK(c, hipMalloc(&c->d_out_agg, sizeof(double) * (size_t)r * c->ncell));
+    HIPCHK(c, hipMalloc(&c->d_pb, sizeof(double) * (size_t)PBX_NROW * c->ncell));
+    HIPCHK(c, hipMalloc(&c->d_rowagg, (size_t)r));
+  }
+  HIPCHK(c, copy_on(c->stream, c->d_rowagg, rowagg.data(), (size_t)r, hipMemcpyHostToDevice));
+  HIPCHK(c, fill_on(c->stream, c->d_out_data, 0, sizeof(double) * (size_t)r * c->ncell));
+  HIPCHK(c, fill_on(c->stream, c->d_out_agg, 0, sizeof(double) * (size_t)r * c->ncell));
+  HIPCHK(c, fill_on(c->stream, c->d_pb, 0, sizeof(double) * (size_t)PBX_NROW * c->ncell));
+  c->put_on = true;
+  return VICGPU_OK;
+}
+
+int vicgpu_put_data_init(vicgpu_ctx* c) {
+  if (!c) return VICGPU_ERR_ARG;
+  if (!c->domain_ready || !c->put_on || !c->d_veglib) return VICGPU_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_put_data(c, c->stream, 0, c->ncell, -1));
+  return VICGPU_OK;
+}
+
+__global__ __launch_bounds__(256) void vic_out_rows_f32(const double* __restrict__ src, const int* __restrict__ rows, int nrows, int ncell,
+                                                         float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)nrows * ncell) return;
+  const int r = (int)(i / ncell), cc = (int)(i % ncell);
+  dst[i] = (float)src[(size_t)rows[r] * ncell + cc];                       // WriteOutputNetCDF.c:387-455 writes floats
+}
+
+// the rows of the listed variables, in the order asked for; -1 when an id is out of range
+static int out_rows(const vicgpu_ctx* c, int nvar, const int* ids, std::vector<int>& rows) {
+  rows.clear();
+  for (int k = 0; k < nvar; k++) {
+    if (ids[k] < 0 || ids[k] >= VOUT_NVAR) return -1;
+    for (int r = c->out_lay.off[ids[k]]; r < c->out_lay.off[ids[k] + 1]; r++) rows.push_back(r);
+  }
+  return (int)rows.size();
+}
+
+int vicgpu_get_outputs(vicgpu_ctx* c, int nvar, const int* var_ids, float* out, int reset) {
+  if (!c || nvar < 0 || (nvar > 0 && (!var_ids || !out))) return VICGPU_ERR_ARG;
+  if (!c->put_on) return VICGPU_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<int> rows;
+  const int nr = out_rows(c, nvar, var_ids, rows);
+  if (nr < 0) return VICGPU_ERR_ARG;
+  if (nr > 0) {
+    int* d_rows = nullptr;
+    float* d_f = nullptr;
+    const size_t n = (size_t)nr * c->ncell;
+    HIPCHK(c, hipMalloc(&d_rows, sizeof(int) * nr));
+    hipError_t e = hipMalloc(&d_f, sizeof(float) * n);
+    if (e == hipSuccess) e = copy_on(c->stream, d_rows, rows.data(), sizeof(int) * nr, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(vic_out_rows_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_out_agg, d_rows, nr, c->ncell, d_f);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = copy_on(c->stream, out, d_f, sizeof(float) * n, hipMemcpyDeviceToHost);
+    HIPIGN(hipFree(d_rows)); HIPIGN(hipFree(d_f));
+    HIPCHK(c, e);
+  }
+  if (reset) HIPCHK(c, fill_on(c->stream, c->d_out_agg, 0, sizeof(double) * (size_t)c->out_nrow * c->ncell));   // vicNl.c:599-606
+  return VICGPU_OK;
+}
+
+int vicgpu_get_output_data(vicgpu_ctx* c, int nvar, const int* var_ids, int which, double* out) {
+  if (!c || nvar <= 0 || !var_ids || !out || which < 0 || which > 1) return VICGPU_ERR_ARG;
+  if (!c->put_on) return VICGPU_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  size_t at = 0;
+  for (int k = 0; k < nvar; k++) {
+    if (var_ids[k] < 0 || var_ids[k] >= VOUT_NVAR) return VICGPU_ERR_ARG;
+    const int r0 = c->out_lay.off[var_ids[k]], ne = c->out_lay.off[var_ids[k] + 1] - r0;
+    HIPCHK(c, copy_on(c->stream, out + at, (which ? c->d_out_agg : c->d_out_data) + (size_t)r0 * c->ncell, sizeof(double) * (size_t)ne * c->ncell, hipMemcpyDeviceToHost));
+    at += (size_t)ne * c->ncell;
+  }
+  return VICGPU_OK;
+}
+
+int vicgpu_get_balance(vicgpu_ctx* c, double* pb) {
+  if (!c || !pb) return VICGPU_ERR_ARG;
+  if (!c->put_on) return VICGPU_ERR_STATE;
+  return d2h(c, pb, c->d_pb, sizeof(double) * (size_t)PB_NROW * c->ncell);
+}
+
+int vicgpu_set_fluxes(vicgpu_ctx* c, const double* flux) {
+  if (!c || !flux) return VICGPU_ERR_ARG;
+  if (!c->domain_ready) return VICGPU_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, copy_on(c->stream, c->d_flux, flux, sizeof(double) * FX_NROW * c->nhru, hipMemcpyHostToDevice));
+  return VICGPU_OK;
 }
 
 }  // extern "C"

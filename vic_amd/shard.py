@@ -70,8 +70,9 @@ def gather_cell_table(local, ncell_per_rank, group=None, device=None):
     world = dist.get_world_size(group)
     nrow = local.shape[0]
     nmax = int(max(ncell_per_rank))
-    t = torch.zeros((nrow, nmax), dtype=torch.float64, device=device)
-    t[:, :local.shape[1]] = torch.as_tensor(np.ascontiguousarray(local), dtype=torch.float64).to(t.device)
+    src = torch.as_tensor(np.ascontiguousarray(local))          # keeps the table's dtype (float32 writer tables, float64 accumulators)
+    t = torch.zeros((nrow, nmax), dtype=src.dtype, device=device)
+    t[:, :local.shape[1]] = src.to(t.device)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t, group=group)
     parts = [o[:, :int(n)].cpu().numpy() for o, n in zip(out, ncell_per_rank)]
