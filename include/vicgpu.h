@@ -303,6 +303,39 @@ int vicgpu_set_domain(vicgpu_ctx *ctx, int ncell, int nhru,
 int vicgpu_set_state(vicgpu_ctx *ctx, const double *state_d, const int *state_i);
 int vicgpu_get_state(vicgpu_ctx *ctx, double *state_d, int *state_i);
 
+/* The same state as the reference's state file holds it (write_model_state.c:95-337, processCellForStateFile): one record
+ * per HRU, HRUs in cell-major hruList order (cell_hru_list order), every value as a double, fields in the order the
+ * StateIO stream sees them (SR_*; node arrays Nnode long).  vicgpu_get_state_records gathers the records on the device
+ * (the write side: the host streams them through its StateIO back-end unchanged); vicgpu_set_state_records is the read
+ * side (read_initial_model_state.c): it scatters the persisted fields into the state and flux tables and leaves every
+ * other row as it is -- like the reference, whose reader fills the HRUs initialize_model_state has just initialised.
+ * Band and vegetation class of every record must match the domain (the reference throws, write_model_state.c:179-188):
+ * VICGPU_ERR_ARG otherwise, with nothing scattered. */
+enum {
+  SR_BAND_INDEX = 0, SR_VEG_CLASS,
+  SR_MOIST0, SR_MOIST1, SR_MOIST2, SR_ICE0, SR_ICE1, SR_ICE2,
+  SR_WDEW,                       /* not in the stream of an artificial bare-soil HRU (write_model_state.c:240-242) */
+  SR_SNOW_CANOPY, SR_SNOW_DENSITY, SR_SNOW_DEPTH, SR_SNOW_PACK_WATER, SR_SNOW_SURF_WATER, SR_SNOW_SWQ,
+  SR_GLAC_WATER_STORAGE, SR_GLAC_CUM_MASS_BALANCE,
+  SR_ENERGY_T                    /* Nnode values; the fields after it are addressed with VICGPU_SR() */
+};
+/* position of the fields that follow the first node array */
+enum {
+  SRT_TFOLIAGE = 0, SRT_GLAC_SURF_TEMP, SRT_SNOW_COLD_CONTENT, SRT_SNOW_PACK_TEMP, SRT_SNOW_SURF_TEMP, SRT_SNOW_ALBEDO,
+  SRT_SNOW_LAST_SNOW, SRT_SNOW_MELTING, SRT_TCANOPY_FBCOUNT,
+  SRT_T_FBCOUNT                  /* Nnode values */
+};
+enum {
+  SRU_TFOLIAGE_FBCOUNT = 0, SRU_TSURF_FBCOUNT, SRU_GLAC_SURF_TEMP_FBCOUNT, SRU_SNOW_SURF_TEMP_FBCOUNT,
+  SRU_GLAC_SURF_TEMP_FBFLAG, SRU_GLAC_VAPOR_FLUX, SRU_SNOW_CANOPY_ALBEDO, SRU_SNOW_SURFACE_FLUX, SRU_SNOW_SURF_TEMP_FBFLAG,
+  SRU_SNOW_TMP_INT_STORAGE, SRU_SNOW_VAPOR_FLUX, SRU_NFIELD
+};
+#define VICGPU_SR_T(f, Nn)   (SR_ENERGY_T + (Nn) + (f))                  /* SRT_* field */
+#define VICGPU_SR_U(f, Nn)   (SR_ENERGY_T + (Nn) + SRT_T_FBCOUNT + (Nn) + (f))   /* SRU_* field */
+#define VICGPU_SR_LEN(Nn)    VICGPU_SR_U(SRU_NFIELD, Nn)
+int vicgpu_get_state_records(vicgpu_ctx *ctx, double *records);         /* [nhru][VICGPU_SR_LEN(Nnode)] */
+int vicgpu_set_state_records(vicgpu_ctx *ctx, const double *records);
+
 /* ---- forcing chunk: replaces cell.atmos[rec] (initialize_atmos.c) for steps
  * [0, nsteps) of the chunk; copied to the device asynchronously on the copy stream. */
 int vicgpu_push_forcing(vicgpu_ctx *ctx, int nsteps,

@@ -604,6 +604,50 @@ int vicorc_set_state(void *hv, const double *sd, const int *si) {
   return 0;
 }
 
+/* The state as the reference's state file holds it: one record per HRU in hruList order, fields in the order
+ * processCellForStateFile streams them (write_model_state.c:166-285; include/vicgpu.h SR_*).  write != 0: HRUs -> records;
+ * otherwise records -> HRUs (the read side of the same function); returns 1 + index of the first record whose band or
+ * vegetation class does not match (write_model_state.c:179-188), with nothing read. */
+int vicorc_state_records(void *hv, double *rec, int write) {
+  vicorc_handle *h = (vicorc_handle *)hv;
+  const int Nn = h->model.opt.Nnode, L = VICGPU_SR_LEN(Nn);
+  int k, l, n;
+  if (!write)
+    for (k = 0; k < h->nhru; k++) {
+      const orc_hru *u = &h->hru[h->cell_list[k]];
+      if ((int)rec[(size_t)k * L + SR_BAND_INDEX] != u->band || (int)rec[(size_t)k * L + SR_VEG_CLASS] != u->veg_class) return k + 1;
+    }
+#define X(slot, field) do { if (write) r[slot] = (field); else (field) = r[slot]; } while (0)
+  for (k = 0; k < h->nhru; k++) {
+    orc_hru *u = &h->hru[h->cell_list[k]];
+    orc_energy *e = &u->energy; orc_snow *s = &u->snow; orc_glac *g = &u->glac;
+    double *r = rec + (size_t)k * L;
+    if (write) { r[SR_BAND_INDEX] = u->band; r[SR_VEG_CLASS] = u->veg_class; }
+    for (l = 0; l < 3; l++) { X(SR_MOIST0 + l, u->layer[l].moist); X(SR_ICE0 + l, u->layer[l].ice); }
+    X(SR_WDEW, u->veg.Wdew);
+    X(SR_SNOW_CANOPY, s->snow_canopy); X(SR_SNOW_DENSITY, s->density); X(SR_SNOW_DEPTH, s->depth); X(SR_SNOW_PACK_WATER, s->pack_water);
+    X(SR_SNOW_SURF_WATER, s->surf_water); X(SR_SNOW_SWQ, s->swq);
+    X(SR_GLAC_WATER_STORAGE, g->water_storage); X(SR_GLAC_CUM_MASS_BALANCE, g->cum_mass_balance);
+    for (n = 0; n < Nn; n++) { X(SR_ENERGY_T + n, e->T[n]); X(VICGPU_SR_T(SRT_T_FBCOUNT, Nn) + n, e->T_fbcount[n]); }
+    X(VICGPU_SR_T(SRT_TFOLIAGE, Nn), e->Tfoliage); X(VICGPU_SR_T(SRT_GLAC_SURF_TEMP, Nn), g->surf_temp);
+    X(VICGPU_SR_T(SRT_SNOW_COLD_CONTENT, Nn), s->coldcontent); X(VICGPU_SR_T(SRT_SNOW_PACK_TEMP, Nn), s->pack_temp);
+    X(VICGPU_SR_T(SRT_SNOW_SURF_TEMP, Nn), s->surf_temp); X(VICGPU_SR_T(SRT_SNOW_ALBEDO, Nn), s->albedo);
+    X(VICGPU_SR_T(SRT_SNOW_LAST_SNOW, Nn), s->last_snow); X(VICGPU_SR_T(SRT_SNOW_MELTING, Nn), s->MELTING);
+    X(VICGPU_SR_T(SRT_TCANOPY_FBCOUNT, Nn), e->Tcanopy_fbcount);
+    X(VICGPU_SR_U(SRU_TFOLIAGE_FBCOUNT, Nn), e->Tfoliage_fbcount); X(VICGPU_SR_U(SRU_TSURF_FBCOUNT, Nn), e->Tsurf_fbcount);
+    X(VICGPU_SR_U(SRU_GLAC_SURF_TEMP_FBCOUNT, Nn), g->surf_temp_fbcount); X(VICGPU_SR_U(SRU_SNOW_SURF_TEMP_FBCOUNT, Nn), s->surf_temp_fbcount);
+    X(VICGPU_SR_U(SRU_GLAC_SURF_TEMP_FBFLAG, Nn), g->surf_temp_fbflag);
+    X(VICGPU_SR_U(SRU_GLAC_VAPOR_FLUX, Nn), g->vapor_flux);
+    if (write) r[VICGPU_SR_U(SRU_SNOW_CANOPY_ALBEDO, Nn)] = 0.0;   /* initialize_snow.c:62, never assigned again */
+    X(VICGPU_SR_U(SRU_SNOW_SURFACE_FLUX, Nn), s->surface_flux);
+    X(VICGPU_SR_U(SRU_SNOW_SURF_TEMP_FBFLAG, Nn), s->surf_temp_fbflag);
+    X(VICGPU_SR_U(SRU_SNOW_TMP_INT_STORAGE, Nn), s->tmp_int_storage);
+    X(VICGPU_SR_U(SRU_SNOW_VAPOR_FLUX, Nn), s->vapor_flux);
+  }
+#undef X
+  return 0;
+}
+
 static void export_flux(vicorc_handle *h, double *fx) {
   const size_t nh = h->nhru;
   int g, l, p;

@@ -188,6 +188,25 @@ class RefModel(_Model):
             out[name.value.decode()] = (v, ne.value, ag.value)
         return out
 
+    def state_stream(self):
+        """The reference's own state-file stream of every cell (processCellForStateFile into a memory back-end):
+        (values, variable ids, cell_start[ncell + 1])."""
+        f = self.lib.vicref_state_stream_write; f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, _dp, _ip, ctypes.c_int, _ip]
+        n = f(self.h, None, None, 0, None)
+        vals = np.zeros(n); ids = np.zeros(n, dtype=np.int32); start = np.zeros(self.dom.ncell + 1, dtype=np.int32)
+        assert f(self.h, _d(vals), _i(ids), n, _i(start)) == n
+        return vals, ids, start
+
+    def read_state_stream(self, vals, ids):
+        f = self.lib.vicref_state_stream_read; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, _dp, _ip, ctypes.c_int]
+        vals = np.ascontiguousarray(vals, dtype=np.float64); ids = np.ascontiguousarray(ids, dtype=np.int32)
+        return f(self.h, _d(vals), _i(ids), len(vals))
+
+    def state_var_id(self, name):
+        f = self.lib.vicref_state_var_id; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_char_p]
+        return f(name.encode())
+
     def get_output(self, name, agg=False):
         """OutputData.data (or .aggdata) of a variable of the reference's list by name: [nelem][ncell]."""
         v, ne, _ = self.output_list()[name]
@@ -199,6 +218,18 @@ class RefModel(_Model):
 
 class OracleModel(_Model):
     prefix = "vicorc_"
+
+    def get_state_records(self):
+        from vic_amd import abi
+        rec = np.zeros((self.dom.nhru, abi.sr_len(self.dom.opt.Nnode)))
+        f = self.lib.vicorc_state_records; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int]
+        assert f(self.h, _d(rec), 1) == 0
+        return rec
+
+    def set_state_records(self, rec):
+        rec = np.ascontiguousarray(rec, dtype=np.float64)
+        f = self.lib.vicorc_state_records; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int]
+        return f(self.h, _d(rec), 0)
 
     def __init__(self, dom, converged_nodes=False):
         """converged_nodes: the frozen-node root finds (soil_thermal_eqn.c) iterate to 1e-13 K instead of the reference's

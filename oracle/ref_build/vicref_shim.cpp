@@ -48,6 +48,41 @@ static inline double cpv(const vicref_handle *h, int row, int c) { return h->cp[
 /* accumulateGlacierMassBalance.c:5 (C++ linkage, not declared in a header) */
 void resetAccumulationValues(std::vector<HRU>* hruList);
 
+/* ---- the reference's own state-file stream (processCellForStateFile, write_model_state.c:105-337) into / out of memory:
+ * a StateIO back-end that records every value the function hands it, with the variable id, instead of formatting it.
+ * Pins the record order of vicgpu_get_state_records / vicorc_state_records. */
+class VicrefBufferIO : public StateIO {
+public:
+  std::vector<double> vals;
+  std::vector<int> ids;
+  size_t at = 0;
+  VicrefBufferIO(IOType t, const ProgramState *st) : StateIO("(memory)", t, st) {}
+  void initializeOutput() {}
+  template <typename T> int put(const T *d, int n, int id) { for (int i = 0; i < n; i++) { vals.push_back((double)d[i]); ids.push_back(id); } return n; }
+  template <typename T> int get(T *d, int n, int id) {
+    for (int i = 0; i < n; i++) {
+      if (at >= vals.size() || ids[at] != id) throw VICException("VicrefBufferIO: stream out of step");
+      d[i] = (T)vals[at++];
+    }
+    return n;
+  }
+  int write(const int *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return put(d, n, id); }
+  int write(const double *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return put(d, n, id); }
+  int write(const float *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return put(d, n, id); }
+  int write(const char *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return put(d, n, id); }
+  int write(const bool *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return put(d, n, id); }
+  int read(int *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return get(d, n, id); }
+  int read(double *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return get(d, n, id); }
+  int read(float *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return get(d, n, id); }
+  int read(bool *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return get(d, n, id); }
+  int read(char *d, int n, const StateVariables::StateMetaDataVariableIndices id) { return get(d, n, id); }
+  StateHeader readHeader() { return StateHeader(0, 0, 0, 0, 0); }
+  int seekToCell(int, int *, int *) { return 0; }
+  void flush() {}
+  void rewindFile() {}
+};
+
+
 extern "C" {
 
 void *vicref_create(const vicgpu_options *opt) {
@@ -470,6 +505,41 @@ int vicref_step(void *hv, const double *forcing, const unsigned char *snowflag, 
 }
 
 int vicref_get_fluxes(void *hv, double *flux) { export_flux((vicref_handle *)hv, flux, NULL, NULL); return 0; }
+
+/* write: streams every cell (cell order) and returns the number of values; vals / ids may be NULL to ask for the count.
+ * cell_start[ncell+1] receives where each cell's values begin. */
+int vicref_state_stream_write(void *hv, double *vals, int *ids, int cap, int *cell_start) {
+  vicref_handle *h = (vicref_handle *)hv;
+  VicrefBufferIO io(StateIO::Writer, &h->state);
+  for (int c = 0; c < h->ncell; c++) {
+    if (cell_start) cell_start[c] = (int)io.vals.size();
+    processCellForStateFile(&h->cells[c], &io, &h->state);
+  }
+  if (cell_start) cell_start[h->ncell] = (int)io.vals.size();
+  if (vals && ids) {
+    if ((int)io.vals.size() > cap) return -1;
+    for (size_t i = 0; i < io.vals.size(); i++) { vals[i] = io.vals[i]; ids[i] = io.ids[i]; }
+  }
+  return (int)io.vals.size();
+}
+/* read: feeds a stream (as written above) back through the same function in Reader mode */
+int vicref_state_stream_read(void *hv, const double *vals, const int *ids, int n) {
+  vicref_handle *h = (vicref_handle *)hv;
+  VicrefBufferIO io(StateIO::Reader, &h->state);
+  io.vals.assign(vals, vals + n); io.ids.assign(ids, ids + n);
+  try {
+    for (int c = 0; c < h->ncell; c++) processCellForStateFile(&h->cells[c], &io, &h->state);
+  } catch (VICException &e) { return -1; }
+  return io.at == (size_t)n ? 0 : -2;
+}
+/* the ids the tests need to find their way through the stream */
+int vicref_state_var_id(const char *name) {
+  using namespace StateVariables;
+  struct { const char *n; int v; } t[] = {{"HRU_BAND_INDEX", HRU_BAND_INDEX}, {"HRU_VEG_INDEX", HRU_VEG_INDEX}, {"SOIL_DZ_NODE", SOIL_DZ_NODE},
+    {"SOIL_ZSUM_NODE", SOIL_ZSUM_NODE}, {"GLAC_MASS_BALANCE_EQN_TERMS", GLAC_MASS_BALANCE_EQN_TERMS}, {"HRU_VEG_VAR_WDEW", HRU_VEG_VAR_WDEW}};
+  for (size_t i = 0; i < sizeof(t) / sizeof(t[0]); i++) if (strcmp(name, t[i].n) == 0) return t[i].v;
+  return -1;
+}
 
 /* ---- the reference's own put_data (put_data.c:7) on the harness's cells, for pinning oracle/orc_putdata.c.
  * rec < 0: the initialisation call of vicNl.c:524-541; otherwise the harness keeps ONE atmos record per cell, so the

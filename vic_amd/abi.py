@@ -101,6 +101,19 @@ def si_nrow(Nn):
     return C["SI_NSCALAR"] + C["SIN_NFIELD"] * Nn
 
 
+def sr_t(f, Nn):
+    """Position of an SRT_* field of a state-file record (VICGPU_SR_T)."""
+    return C["SR_ENERGY_T"] + Nn + f
+
+
+def sr_u(f, Nn):
+    return C["SR_ENERGY_T"] + Nn + C["SRT_T_FBCOUNT"] + Nn + f
+
+
+def sr_len(Nn):
+    return sr_u(C["SRU_NFIELD"], Nn)
+
+
 class Options(ctypes.Structure):
     """struct vicgpu_options (include/vicgpu.h)."""
     _fields_ = [

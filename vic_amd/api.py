@@ -61,6 +61,8 @@ def load_library():
         "vicgpu_last_kernel_ms": (ctypes.c_int, [vp, _dp, _ip]),
         "vicgpu_debug_pure": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
         "vicgpu_glacier_mass_balance_fit": (ctypes.c_int, [vp, _dp, ctypes.c_int]),
+        "vicgpu_get_state_records": (ctypes.c_int, [vp, _dp]),
+        "vicgpu_set_state_records": (ctypes.c_int, [vp, _dp]),
         # include/vicgpu_out.h
         "vicgpu_out_nvar": (ctypes.c_int, []),
         "vicgpu_out_var_id": (ctypes.c_int, [ctypes.c_char_p]),
@@ -93,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "vicgpu_glacier_mass_balance_fit",
     "vicgpu_out_nvar", "vicgpu_out_var_id", "vicgpu_out_var_name", "vicgpu_out_var_kind", "vicgpu_out_var_agg", "vicgpu_out_var_nelem",
     "vicgpu_put_data_config", "vicgpu_put_data_init", "vicgpu_get_outputs", "vicgpu_get_output_data", "vicgpu_get_balance",
-    "vicgpu_set_fluxes",
+    "vicgpu_set_fluxes", "vicgpu_get_state_records", "vicgpu_set_state_records",
 ]
 
 
@@ -199,6 +201,17 @@ class Model:
 
     def set_write_fluxes(self, on):
         self._chk(self.lib.vicgpu_set_write_fluxes(self.h, int(bool(on))))
+
+    # ---- the state as the reference's state file holds it (write_model_state.c:95-337)
+    def get_state_records(self):
+        rec = np.zeros((self.dom.nhru, abi.sr_len(self.opt.Nnode)))
+        self._chk(self.lib.vicgpu_get_state_records(self.h, _d(rec)))
+        return rec
+
+    def set_state_records(self, rec):
+        rec = np.ascontiguousarray(rec, dtype=np.float64)
+        assert rec.shape == (self.dom.nhru, abi.sr_len(self.opt.Nnode))
+        self._chk(self.lib.vicgpu_set_state_records(self.h, _d(rec)))
 
     # ---- put_data: the aggregated output variables (include/vicgpu_out.h)
     def output_list(self):

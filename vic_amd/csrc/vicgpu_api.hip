@@ -942,6 +942,59 @@ __global__ __launch_bounds__(256) void vic_cell_reduce(const CArgs a) {
   a.cell_err[c] |= err;
 }
 
+// ------------------------------------------------------------------------------------------------ state-file records
+// One lane per HRU in hruList order: the HRU's values in the order processCellForStateFile streams them
+// (write_model_state.c:166-285).  GATHER = false is the read side; lanes whose band / vegetation class do not match the
+// record count themselves in *mismatch and scatter nothing.
+struct RArgs {
+  int nhru, Nn;
+  const int* cell_list;
+  const int* hpi;
+  double* sd;
+  int* si;
+  double* flux;
+  double* rec;
+  int* mismatch;
+};
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void vic_state_records(const RArgs a) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= a.nhru) return;
+  const int g = a.cell_list[k], Nn = a.Nn;
+  const size_t nh = a.nhru;
+  double* r = a.rec + (size_t)k * VICGPU_SR_LEN(Nn);
+  const int band = a.hpi[(size_t)HPI_BAND * nh + g], vegc = a.hpi[(size_t)HPI_VEG_CLASS * nh + g];
+  if (GATHER) { r[SR_BAND_INDEX] = band; r[SR_VEG_CLASS] = vegc; }
+  else if ((int)r[SR_BAND_INDEX] != band || (int)r[SR_VEG_CLASS] != vegc) { atomicAdd(a.mismatch, 1); return; }
+#define D(slot, row) do { if (GATHER) r[slot] = a.sd[(size_t)(row) * nh + g]; else a.sd[(size_t)(row) * nh + g] = r[slot]; } while (0)
+#define I(slot, row) do { if (GATHER) r[slot] = a.si[(size_t)(row) * nh + g]; else a.si[(size_t)(row) * nh + g] = (int)r[slot]; } while (0)
+#define F(slot, row) do { if (GATHER) r[slot] = a.flux[(size_t)(row) * nh + g]; else a.flux[(size_t)(row) * nh + g] = r[slot]; } while (0)
+  for (int l = 0; l < 3; l++) { D(SR_MOIST0 + l, SD_MOIST0 + l); D(SR_ICE0 + l, SD_ICE0 + l); }
+  D(SR_WDEW, SD_WDEW);
+  D(SR_SNOW_CANOPY, SD_SNOW_CANOPY); D(SR_SNOW_DENSITY, SD_SNOW_DENSITY); D(SR_SNOW_DEPTH, SD_SNOW_DEPTH);
+  D(SR_SNOW_PACK_WATER, SD_SNOW_PACK_WATER); D(SR_SNOW_SURF_WATER, SD_SNOW_SURF_WATER); D(SR_SNOW_SWQ, SD_SNOW_SWQ);
+  D(SR_GLAC_WATER_STORAGE, SD_GLAC_WATER_STORAGE); D(SR_GLAC_CUM_MASS_BALANCE, SD_GLAC_CUM_MASS_BALANCE);
+  for (int n = 0; n < Nn; n++) { D(SR_ENERGY_T + n, VICGPU_SD_NODE(SDN_T, n, Nn)); I(VICGPU_SR_T(SRT_T_FBCOUNT, Nn) + n, VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn)); }
+  D(VICGPU_SR_T(SRT_TFOLIAGE, Nn), SD_TFOLIAGE); D(VICGPU_SR_T(SRT_GLAC_SURF_TEMP, Nn), SD_GLAC_SURF_TEMP);
+  D(VICGPU_SR_T(SRT_SNOW_COLD_CONTENT, Nn), SD_SNOW_COLDCONTENT); D(VICGPU_SR_T(SRT_SNOW_PACK_TEMP, Nn), SD_SNOW_PACK_TEMP);
+  D(VICGPU_SR_T(SRT_SNOW_SURF_TEMP, Nn), SD_SNOW_SURF_TEMP); D(VICGPU_SR_T(SRT_SNOW_ALBEDO, Nn), SD_SNOW_ALBEDO);
+  I(VICGPU_SR_T(SRT_SNOW_LAST_SNOW, Nn), SI_SNOW_LAST_SNOW); I(VICGPU_SR_T(SRT_SNOW_MELTING, Nn), SI_SNOW_MELTING);
+  I(VICGPU_SR_T(SRT_TCANOPY_FBCOUNT, Nn), SI_TCANOPY_FBCOUNT);
+  I(VICGPU_SR_U(SRU_TFOLIAGE_FBCOUNT, Nn), SI_TFOLIAGE_FBCOUNT); I(VICGPU_SR_U(SRU_TSURF_FBCOUNT, Nn), SI_TSURF_FBCOUNT);
+  I(VICGPU_SR_U(SRU_GLAC_SURF_TEMP_FBCOUNT, Nn), SI_GLAC_SURF_TEMP_FBCOUNT); I(VICGPU_SR_U(SRU_SNOW_SURF_TEMP_FBCOUNT, Nn), SI_SNOW_SURF_TEMP_FBCOUNT);
+  I(VICGPU_SR_U(SRU_GLAC_SURF_TEMP_FBFLAG, Nn), SI_GLAC_SURF_TEMP_FBFLAG);
+  F(VICGPU_SR_U(SRU_GLAC_VAPOR_FLUX, Nn), FX_GLAC_VAPOR_FLUX);
+  if (GATHER) r[VICGPU_SR_U(SRU_SNOW_CANOPY_ALBEDO, Nn)] = 0.0;            // snow.canopy_albedo: initialize_snow.c:62, never assigned again
+  F(VICGPU_SR_U(SRU_SNOW_SURFACE_FLUX, Nn), FX_SNOW_SURFACE_FLUX);
+  I(VICGPU_SR_U(SRU_SNOW_SURF_TEMP_FBFLAG, Nn), SI_SNOW_SURF_TEMP_FBFLAG);
+  D(VICGPU_SR_U(SRU_SNOW_TMP_INT_STORAGE, Nn), SD_SNOW_TMP_INT_STORAGE);
+  F(VICGPU_SR_U(SRU_SNOW_VAPOR_FLUX, Nn), FX_SNOW_VAPOR_FLUX);
+#undef D
+#undef I
+#undef F
+}
+
 // ------------------------------------------------------------------------------------------------ context
 // A chunk of cells with all their HRUs.  Cells never interact, so every chunk runs the whole step sequence on its own
 // stream, driven by its own host thread: while one chunk is in the thin tail of its Brent rounds (a few stragglers,
@@ -1674,6 +1727,53 @@ void* vicgpu_device_ptr(vicgpu_ctx* c, int which) {
     default: return nullptr;
   }
 }
+
+static int state_records(vicgpu_ctx* c, double* host, bool gather) {
+  if (!c || !host) return VICGPU_ERR_ARG;
+  if (!c->domain_ready) return VICGPU_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t bytes = sizeof(double) * (size_t)VICGPU_SR_LEN(c->opt.Nnode) * c->nhru;
+  double* d_rec = nullptr;
+  int* d_mis = nullptr;
+  HIPCHK(c, hipMalloc(&d_rec, bytes));
+  hipError_t e = hipMalloc(&d_mis, sizeof(int));
+  int mismatch = 0;
+  if (e == hipSuccess) e = fill_on(c->stream, d_mis, 0, sizeof(int));
+  if (e == hipSuccess && !gather) e = copy_on(c->stream, d_rec, host, bytes, hipMemcpyHostToDevice);
+  RArgs a;
+  a.nhru = c->nhru; a.Nn = c->opt.Nnode; a.cell_list = c->d_cell_list; a.hpi = c->d_hpi; a.sd = c->d_sd; a.si = c->d_si;
+  a.flux = c->d_flux; a.rec = d_rec; a.mismatch = d_mis;
+  if (e == hipSuccess && !gather) {
+    // read side, pass 1: validate every record before anything is scattered (a reader that throws changes nothing)
+    std::vector<int> hpi_band(c->nhru), hpi_veg(c->nhru), list(c->nhru);
+    e = copy_on(c->stream, hpi_band.data(), c->d_hpi + (size_t)HPI_BAND * c->nhru, sizeof(int) * c->nhru, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = copy_on(c->stream, hpi_veg.data(), c->d_hpi + (size_t)HPI_VEG_CLASS * c->nhru, sizeof(int) * c->nhru, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = copy_on(c->stream, list.data(), c->d_cell_list, sizeof(int) * c->nhru, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+      const size_t L = VICGPU_SR_LEN(c->opt.Nnode);
+      for (int k = 0; k < c->nhru && !mismatch; k++)
+        if ((int)host[k * L + SR_BAND_INDEX] != hpi_band[list[k]] || (int)host[k * L + SR_VEG_CLASS] != hpi_veg[list[k]]) mismatch = k + 1;
+    }
+  }
+  if (e == hipSuccess && !mismatch) {
+    const unsigned nblk = (unsigned)((c->nhru + 255) / 256);
+    if (gather) hipLaunchKernelGGL(vic_state_records<true>, dim3(nblk), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(vic_state_records<false>, dim3(nblk), dim3(256), 0, c->stream, a);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && gather) e = copy_on(c->stream, host, d_rec, bytes, hipMemcpyDeviceToHost);
+  }
+  HIPIGN(hipFree(d_rec)); HIPIGN(hipFree(d_mis));
+  HIPCHK(c, e);
+  if (mismatch) {
+    c->err = "state record " + std::to_string(mismatch - 1) + ": band / vegetation class do not match the domain (write_model_state.c:179-188)";
+    return VICGPU_ERR_ARG;
+  }
+  return VICGPU_OK;
+}
+int vicgpu_get_state_records(vicgpu_ctx* c, double* rec) { return state_records(c, rec, true); }
+int vicgpu_set_state_records(vicgpu_ctx* c, const double* rec) { return state_records(c, const_cast<double*>(rec), false); }
 
 // ------------------------------------------------------------------------------------------------ put_data (vicgpu_out.h)
 int vicgpu_out_nvar(void) { return VOUT_NVAR; }
