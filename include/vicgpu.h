@@ -31,6 +31,8 @@
 #ifndef VICGPU_H_
 #define VICGPU_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -131,6 +133,14 @@ enum {
 enum {
   VIC_F_AIR_TEMP = 0, VIC_F_PREC, VIC_F_PRESSURE, VIC_F_VP, VIC_F_VPD,
   VIC_F_DENSITY, VIC_F_SHORTWAVE, VIC_F_LONGWAVE, VIC_F_WIND, VIC_NFORCE
+};
+
+/* The same forcing as the forcing files hold it, hour by hour, before initialize_atmos.c derives atmos[rec] from it:
+ * double[nsteps][VIC_NRAW][dt][ncell] (dt = hours per model step), pressure and vapour pressure in kPa
+ * (initialize_atmos.c:290-295).  vicgpu_prefetch_forcing_raw derives the table above from it on the device. */
+enum {
+  VIC_RAW_AIR_TEMP = 0, VIC_RAW_PREC, VIC_RAW_PRESSURE_KPA, VIC_RAW_VP_KPA, VIC_RAW_SHORTWAVE, VIC_RAW_LONGWAVE, VIC_RAW_WIND,
+  VIC_NRAW
 };
 
 /* dmy_struct (vicNl_def.h:1082-1088): int[nsteps][VIC_NDMY] */
@@ -342,6 +352,29 @@ int vicgpu_push_forcing(vicgpu_ctx *ctx, int nsteps,
                         const double *forcing,          /* [nsteps][VIC_NFORCE][NF+1][ncell] */
                         const unsigned char *snowflag,  /* [nsteps][NF+1][ncell] */
                         const int *dmy);                /* [nsteps][VIC_NDMY] */
+
+/* ---- forcing streaming.  The context holds two forcing chunks: the current one (vicgpu_step indexes it) and a spare.
+ *   vicgpu_prefetch_forcing      starts the upload of the NEXT chunk into the spare (copy stream; returns at once)
+ *   vicgpu_prefetch_forcing_raw  the same from hourly raw forcing (VIC_RAW_*): the device derives what initialize_atmos.c
+ *                                derives per record -- kPa -> Pa (:290-295), the MIN_WIND_SPEED floor (:518-536), air
+ *                                density from pressure (:980-1000, plapse != 0: the PLAPSE form), vpd = svp(T) - vp clipped
+ *                                at 0 (:1175-1193), the snow_step aggregation with the step mean / sum in sub-index NR, and
+ *                                the snowflag (:1275-1303)
+ *   vicgpu_swap_forcing          makes the prefetched chunk the current one (steps already queued keep the old one)
+ * so a driver overlaps the transfer of chunk k+1 with the steps of chunk k:
+ *     push(0);  for k: { prefetch(k+1); step(0, n_k); swap(); }
+ * vicgpu_push_forcing == prefetch + swap.  Host buffers: memory from vicgpu_host_alloc (pinned) is read by DMA while the
+ * steps run and must stay unchanged until vicgpu_swap_forcing returns; any other memory is first copied into the
+ * library's own pinned staging area, so it can be reused as soon as the call returns. */
+int vicgpu_prefetch_forcing(vicgpu_ctx *ctx, int nsteps, const double *forcing, const unsigned char *snowflag, const int *dmy);
+int vicgpu_prefetch_forcing_raw(vicgpu_ctx *ctx, int nsteps,
+                                const double *raw,      /* [nsteps][VIC_NRAW][dt][ncell] */
+                                const int *dmy, double min_wind_speed, int plapse);
+int vicgpu_swap_forcing(vicgpu_ctx *ctx);
+int vicgpu_get_forcing(vicgpu_ctx *ctx, int step, double *forcing /* [VIC_NFORCE][NF+1][ncell] */,
+                       unsigned char *snowflag /* [NF+1][ncell] */);       /* read-back of the current chunk (tests) */
+void *vicgpu_host_alloc(size_t bytes);                  /* pinned host memory for forcing chunks */
+void vicgpu_host_free(void *p);
 
 /* ---- the hot path: for rec in [step0, step0+nsteps): dist_prec for every cell
  * (vicNl.c:506-543).  With QUICK_FLUX the call only enqueues work.  With the

@@ -648,6 +648,63 @@ int vicorc_state_records(void *hv, double *rec, int write) {
   return 0;
 }
 
+/* initialize_atmos.c: atmos[rec] from one record of hourly forcing, for the case every variable is supplied sub-daily
+ * (raw [nsteps][VIC_NRAW][dt][ncell], kPa for the two pressures): kPa -> Pa (:290-295), the snow_step-hour aggregation
+ * with mean / sum in sub-index NR (:886-893 and its siblings), the MIN_WIND_SPEED floor per hour (:518-536), density from
+ * pressure (:980-1000), vpd = svp(T) - vp clipped at 0 with vp reset (:1175-1193), snowflag (:1275-1303).
+ * NOT pinned against the reference: initialize_atmos needs read_atmos_data / the forcing-file machinery, which is not on
+ * the path this repository can build (oracle/ref_build/build_ref.sh). */
+int vicorc_derive_forcing(void *hv, int nsteps, const double *raw, double min_wind, int plapse, double *forcing, unsigned char *snowflag) {
+  vicorc_handle *h = (vicorc_handle *)hv;
+  const vicgpu_options *o = &h->model.opt;
+  const int NF = h->model.NF, NR = h->model.NR, ns = NR + 1, dt = o->dt, ss = o->snow_step;
+  const size_t nc = h->ncell;
+  int s, c, j, hh, b;
+  for (s = 0; s < nsteps; s++)
+    for (c = 0; c < h->ncell; c++) {
+      const orc_soil *sc = &h->soil[c];
+      const double *r = raw + (size_t)s * VIC_NRAW * dt * nc + c;
+      double *f = forcing + (size_t)s * VIC_NFORCE * ns * nc + c;
+      unsigned char *sf = snowflag + (size_t)s * ns * nc + c;
+      double min_Tfactor = sc->Tfactor[0], thr;
+      double sum[VIC_NFORCE] = {0};
+      int any = 0, v;
+      for (b = 1; b < o->Nband; b++) if (sc->Tfactor[b] < min_Tfactor) min_Tfactor = sc->Tfactor[b];
+      thr = (o->TEMP_TH_TYPE == VIC_TEMP_TH_KIENZLE) ? (sc->MAX_SNOW_TEMP + sc->MIN_RAIN_TEMP / 2) : sc->MAX_SNOW_TEMP;
+#define RAW(v, h) r[((size_t)(v) * dt + (h)) * nc]
+#define FO(v, j) f[((size_t)(v) * ns + (j)) * nc]
+      for (j = 0; j < NF; j++) {
+        double T = 0, prec = 0, pr = 0, vp = 0, sw = 0, lw = 0, wind = 0, dens, vpd;
+        int snow;
+        for (hh = j * ss; hh < (j + 1) * ss; hh++) {
+          double w = RAW(VIC_RAW_WIND, hh);
+          T += RAW(VIC_RAW_AIR_TEMP, hh); prec += RAW(VIC_RAW_PREC, hh);
+          pr += RAW(VIC_RAW_PRESSURE_KPA, hh) * 1000.0; vp += RAW(VIC_RAW_VP_KPA, hh) * 1000.0;
+          sw += RAW(VIC_RAW_SHORTWAVE, hh); lw += RAW(VIC_RAW_LONGWAVE, hh);
+          wind += (w < min_wind) ? min_wind : w;
+        }
+        T /= ss; pr /= ss; vp /= ss; sw /= ss; lw /= ss; wind /= ss;
+        dens = plapse ? pr / (287.0 * (ORC_KELVIN + T)) : 0.003486 * pr / (275.0 + T);
+        vpd = orc_svp(T) - vp;
+        if (vpd < 0) { vpd = 0; vp = orc_svp(T); }
+        FO(VIC_F_AIR_TEMP, j) = T; FO(VIC_F_PREC, j) = prec; FO(VIC_F_PRESSURE, j) = pr; FO(VIC_F_VP, j) = vp; FO(VIC_F_VPD, j) = vpd;
+        FO(VIC_F_DENSITY, j) = dens; FO(VIC_F_SHORTWAVE, j) = sw; FO(VIC_F_LONGWAVE, j) = lw; FO(VIC_F_WIND, j) = wind;
+        snow = ((T + min_Tfactor) < thr) && (prec > 0);
+        sf[(size_t)j * nc] = (unsigned char)snow;
+        any |= snow;
+        sum[VIC_F_AIR_TEMP] += T; sum[VIC_F_PREC] += prec; sum[VIC_F_PRESSURE] += pr; sum[VIC_F_VP] += vp; sum[VIC_F_VPD] += vpd;
+        sum[VIC_F_DENSITY] += dens; sum[VIC_F_SHORTWAVE] += sw; sum[VIC_F_LONGWAVE] += lw; sum[VIC_F_WIND] += wind;
+      }
+      if (NF > 1) {
+        for (v = 0; v < VIC_NFORCE; v++) FO(v, NR) = (v == VIC_F_PREC) ? sum[v] : sum[v] / (double)(float)NF;
+        sf[(size_t)NR * nc] = (unsigned char)any;
+      }
+#undef RAW
+#undef FO
+    }
+  return 0;
+}
+
 static void export_flux(vicorc_handle *h, double *fx) {
   const size_t nh = h->nhru;
   int g, l, p;

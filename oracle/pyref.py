@@ -219,6 +219,16 @@ class RefModel(_Model):
 class OracleModel(_Model):
     prefix = "vicorc_"
 
+    def derive_forcing(self, raw, min_wind=0.0, plapse=1):
+        """initialize_atmos.c's derivation of atmos[rec] from hourly raw forcing [nsteps][VIC_NRAW][dt][ncell]."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        nsub = self.dom.opt.NR + 1
+        f = np.zeros((raw.shape[0], C["VIC_NFORCE"], nsub, self.dom.ncell)); sf = np.zeros((raw.shape[0], nsub, self.dom.ncell), dtype=np.uint8)
+        fn = self.lib.vicorc_derive_forcing; fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte)]
+        assert fn(self.h, raw.shape[0], _d(raw), float(min_wind), int(plapse), _d(f), sf.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))) == 0
+        return f, sf
+
     def get_state_records(self):
         from vic_amd import abi
         rec = np.zeros((self.dom.nhru, abi.sr_len(self.dom.opt.Nnode)))

@@ -61,6 +61,12 @@ def load_library():
         "vicgpu_last_kernel_ms": (ctypes.c_int, [vp, _dp, _ip]),
         "vicgpu_debug_pure": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, _dp, _dp]),
         "vicgpu_glacier_mass_balance_fit": (ctypes.c_int, [vp, _dp, ctypes.c_int]),
+        "vicgpu_prefetch_forcing": (ctypes.c_int, [vp, ctypes.c_int, _dp, _up, _ip]),
+        "vicgpu_prefetch_forcing_raw": (ctypes.c_int, [vp, ctypes.c_int, _dp, _ip, ctypes.c_double, ctypes.c_int]),
+        "vicgpu_swap_forcing": (ctypes.c_int, [vp]),
+        "vicgpu_get_forcing": (ctypes.c_int, [vp, ctypes.c_int, _dp, _up]),
+        "vicgpu_host_alloc": (vp, [ctypes.c_size_t]),
+        "vicgpu_host_free": (None, [vp]),
         "vicgpu_get_state_records": (ctypes.c_int, [vp, _dp]),
         "vicgpu_set_state_records": (ctypes.c_int, [vp, _dp]),
         # include/vicgpu_out.h
@@ -96,6 +102,8 @@ EXPORTED_SYMBOLS = [
     "vicgpu_out_nvar", "vicgpu_out_var_id", "vicgpu_out_var_name", "vicgpu_out_var_kind", "vicgpu_out_var_agg", "vicgpu_out_var_nelem",
     "vicgpu_put_data_config", "vicgpu_put_data_init", "vicgpu_get_outputs", "vicgpu_get_output_data", "vicgpu_get_balance",
     "vicgpu_set_fluxes", "vicgpu_get_state_records", "vicgpu_set_state_records",
+    "vicgpu_prefetch_forcing", "vicgpu_prefetch_forcing_raw", "vicgpu_swap_forcing", "vicgpu_get_forcing", "vicgpu_host_alloc",
+    "vicgpu_host_free",
 ]
 
 
@@ -132,6 +140,9 @@ class Model:
         if getattr(self, "h", None):
             self.lib.vicgpu_destroy(self.h)
             self.h = None
+            for p in getattr(self, "_pinned", []):
+                self.lib.vicgpu_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -164,6 +175,46 @@ class Model:
         assert dmy.shape == (n, C["VIC_NDMY"])
         self._hold = (forcing, snowflag, dmy)   # the H2D copy is asynchronous
         self._chk(self.lib.vicgpu_push_forcing(self.h, n, _d(forcing), snowflag.ctypes.data_as(_up), _i(dmy)))
+
+    # ---- forcing streaming: the next chunk uploads while the steps of the current one run
+    def prefetch_forcing(self, forcing, snowflag, dmy):
+        forcing = np.ascontiguousarray(forcing, dtype=np.float64)
+        snowflag = np.ascontiguousarray(snowflag, dtype=np.uint8)
+        dmy = np.ascontiguousarray(dmy, dtype=np.int32)
+        n = forcing.shape[0]
+        assert forcing.shape == (n, C["VIC_NFORCE"], self.opt.NR + 1, self.dom.ncell), forcing.shape
+        assert snowflag.shape == (n, self.opt.NR + 1, self.dom.ncell)
+        self._hold_next = (forcing, snowflag, dmy)   # pinned sources are read until swap_forcing returns
+        self._chk(self.lib.vicgpu_prefetch_forcing(self.h, n, _d(forcing), snowflag.ctypes.data_as(_up), _i(dmy)))
+
+    def prefetch_forcing_raw(self, raw, dmy, min_wind_speed=0.0, plapse=True):
+        """Hourly raw forcing [nsteps][VIC_NRAW][dt][ncell] (kPa pressures): initialize_atmos.c's derivation runs on the device."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        dmy = np.ascontiguousarray(dmy, dtype=np.int32)
+        n = raw.shape[0]
+        assert raw.shape == (n, C["VIC_NRAW"], self.opt.dt, self.dom.ncell), raw.shape
+        self._hold_next = (raw, dmy)
+        self._chk(self.lib.vicgpu_prefetch_forcing_raw(self.h, n, _d(raw), _i(dmy), float(min_wind_speed), int(bool(plapse))))
+
+    def swap_forcing(self):
+        self._chk(self.lib.vicgpu_swap_forcing(self.h))
+        self._hold = getattr(self, "_hold_next", None)
+
+    def get_forcing(self, step):
+        f = np.zeros((C["VIC_NFORCE"], self.opt.NR + 1, self.dom.ncell)); sf = np.zeros((self.opt.NR + 1, self.dom.ncell), dtype=np.uint8)
+        self._chk(self.lib.vicgpu_get_forcing(self.h, int(step), _d(f), sf.ctypes.data_as(_up)))
+        return f, sf
+
+    def pinned(self, shape, dtype=np.float64):
+        """A numpy array over pinned host memory (vicgpu_host_alloc): forcing chunks in it are uploaded by DMA without a
+        staging copy.  Freed when the Model is closed."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.vicgpu_host_alloc(n)
+        if not p:
+            raise VicGpuError("vicgpu_host_alloc(%d) failed" % n)
+        self._pinned = getattr(self, "_pinned", []) + [p]
+        buf = (ctypes.c_char * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     # ---- the hot path
     def dist_prec(self, rec0, nrec=1, sync=True):

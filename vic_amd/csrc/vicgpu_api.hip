@@ -1026,12 +1026,24 @@ struct vicgpu_ctx {
          *d_cell_out = nullptr, *d_accum = nullptr;
   int *d_hpi = nullptr, *d_si = nullptr, *d_cell_off = nullptr, *d_cell_list = nullptr, *d_hru_err = nullptr, *d_cell_err = nullptr;
   unsigned char* d_snowflag = nullptr;
+  // forcing: d_forcing / d_snowflag / dmy / chunk_steps describe the CURRENT chunk = slot[cur]; the other slot takes the
+  // prefetch of the next one (vicgpu_prefetch_forcing*, vicgpu_swap_forcing)
   std::vector<int> dmy;            // host copy [nsteps][VIC_NDMY]
   int chunk_steps = 0;
-  size_t forcing_cap = 0, snowflag_cap = 0;
+  struct ForcingSlot {
+    double *d_f = nullptr, *d_raw = nullptr;
+    unsigned char* d_s = nullptr;
+    size_t fcap = 0, scap = 0, rawcap = 0, stage_cap = 0;
+    void* h_stage = nullptr;       // pinned staging for pageable sources
+    std::vector<int> dmy;
+    int nsteps = 0;
+    hipEvent_t uploaded = nullptr; // copy stream: the chunk is in the slot
+    hipEvent_t released = nullptr; // context stream: every step that read the slot has been queued before it
+    bool upload_pending = false, was_current = false;
+  } slot[2];
+  int cur = -1, staged = -1;
   hipStream_t stream = nullptr, copy_stream = nullptr;
   bool own_stream = true;
-  hipEvent_t forcing_ready = nullptr;
   std::vector<hipEvent_t> ev;      // start/stop pairs of the last vicgpu_step call
   int ev_used = 0;
   int write_fluxes = 1;
@@ -1073,6 +1085,8 @@ static void free_domain(vicgpu_ctx* c) {
   c->domain_ready = false;
   c->chunk_steps = 0;              // a forcing chunk belongs to the domain it was pushed for (its rows are ncell wide)
   c->dmy.clear();
+  c->cur = c->staged = -1;
+  c->d_forcing = nullptr; c->d_snowflag = nullptr;
   c->d_ctx = nullptr; c->d_pin = c->d_ts = c->d_pout = nullptr; c->d_hstate = c->d_pslot = c->d_hkey = nullptr;
   c->d_cp = c->d_hpd = c->d_sd = c->d_flux = c->d_cell_out = c->d_accum = nullptr;
   c->d_hpi = c->d_si = c->d_cell_off = c->d_cell_list = c->d_hru_err = c->d_cell_err = nullptr;
@@ -1331,7 +1345,10 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) { delete c; return VICGPU_ERR_HIP; }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess
-      || hipEventCreateWithFlags(&c->forcing_ready, hipEventDisableTiming) != hipSuccess) {
+      || hipEventCreateWithFlags(&c->slot[0].uploaded, hipEventDisableTiming) != hipSuccess
+      || hipEventCreateWithFlags(&c->slot[1].uploaded, hipEventDisableTiming) != hipSuccess
+      || hipEventCreateWithFlags(&c->slot[0].released, hipEventDisableTiming) != hipSuccess
+      || hipEventCreateWithFlags(&c->slot[1].released, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return VICGPU_ERR_HIP;
   }
@@ -1349,9 +1366,15 @@ void vicgpu_destroy(vicgpu_ctx* c) {
         fprintf(stderr, "[vicgpu] chunk %zu: %d cells, %d HRUs, %lld steps, %.1f Brent rounds per step\n", k, c->chunks[k].ccount,
                 c->chunks[k].gcount, c->chunks[k].steps, (double)c->chunks[k].rounds / c->chunks[k].steps);
   free_domain(c);
-  HIPIGN(hipFree(c->d_veglib)); HIPIGN(hipFree(c->d_forcing)); HIPIGN(hipFree(c->d_snowflag));
+  HIPIGN(hipFree(c->d_veglib));
+  if (c->copy_stream) HIPIGN(hipStreamSynchronize(c->copy_stream));
+  for (auto& sl : c->slot) {
+    HIPIGN(hipFree(sl.d_f)); HIPIGN(hipFree(sl.d_s)); HIPIGN(hipFree(sl.d_raw));
+    if (sl.h_stage) HIPIGN(hipHostFree(sl.h_stage));
+    if (sl.uploaded) HIPIGN(hipEventDestroy(sl.uploaded));
+    if (sl.released) HIPIGN(hipEventDestroy(sl.released));
+  }
   for (auto e : c->ev) HIPIGN(hipEventDestroy(e));
-  if (c->forcing_ready) HIPIGN(hipEventDestroy(c->forcing_ready));
   if (c->own_stream && c->stream) HIPIGN(hipStreamDestroy(c->stream));
   if (c->copy_stream) HIPIGN(hipStreamDestroy(c->copy_stream));
   delete c;
@@ -1510,43 +1533,191 @@ int vicgpu_get_state(vicgpu_ctx* c, double* sd, int* si) {
   return VICGPU_OK;
 }
 
-int vicgpu_push_forcing(vicgpu_ctx* c, int nsteps, const double* forcing, const unsigned char* snowflag, const int* dmy) {
-  if (!c || nsteps <= 0 || !forcing || !snowflag || !dmy) return VICGPU_ERR_ARG;
+// initialize_atmos.c, the derivation of atmos[rec] from the hourly forcing of one record (see include/vicgpu.h): one lane
+// per (step, cell)
+struct FArgs {
+  int nsteps, ncell, dt, snow_step, NF, NR, temp_th_type, Nband, Nnode, plapse;
+  double min_wind;
+  const double* raw;
+  const double* cell_params;
+  double* forcing;
+  unsigned char* snowflag;
+};
+
+__global__ __launch_bounds__(256) void vic_derive_forcing(const FArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)a.nsteps * a.ncell) return;
+  const int s = (int)(i / a.ncell), c = (int)(i % a.ncell);
+  const size_t nc = a.ncell;
+  const int ns = a.NR + 1, NF = a.NF;
+  const double* raw = a.raw + (size_t)s * VIC_NRAW * a.dt * nc + c;
+  double* f = a.forcing + (size_t)s * VIC_NFORCE * ns * nc + c;
+  unsigned char* sf = a.snowflag + (size_t)s * ns * nc + c;
+#define RAW(v, h) raw[((size_t)(v) * a.dt + (h)) * nc]
+#define F(v, j) f[((size_t)(v) * ns + (j)) * nc]
+  CellView cv{a.cell_params, a.ncell, c, a.Nnode, a.Nband};
+  double min_Tfactor = cv.band(CPB_TFACTOR, 0);                                       // initialize_atmos.c:1275-1280
+  for (int b = 1; b < a.Nband; b++) { const double t = cv.band(CPB_TFACTOR, b); if (t < min_Tfactor) min_Tfactor = t; }
+  const double max_snow = cv.s(CP_MAX_SNOW_TEMP), min_rain = cv.s(CP_MIN_RAIN_TEMP);
+  const double thr = (a.temp_th_type == VIC_TEMP_TH_KIENZLE) ? (max_snow + min_rain / 2) : max_snow;
+  double sT = 0, sP = 0, sPr = 0, sVp = 0, sVpd = 0, sD = 0, sSw = 0, sLw = 0, sW = 0;
+  bool any_snow = false;
+  for (int j = 0; j < NF; j++) {
+    double T = 0, prec = 0, pr = 0, vp = 0, sw = 0, lw = 0, wind = 0;
+    for (int h = j * a.snow_step; h < (j + 1) * a.snow_step; h++) {                   // the snow_step-hour aggregation (:886-893 et al.)
+      T += RAW(VIC_RAW_AIR_TEMP, h); prec += RAW(VIC_RAW_PREC, h);
+      pr += RAW(VIC_RAW_PRESSURE_KPA, h) * 1000.0; vp += RAW(VIC_RAW_VP_KPA, h) * 1000.0;      // kPa2Pa, :290-295
+      sw += RAW(VIC_RAW_SHORTWAVE, h); lw += RAW(VIC_RAW_LONGWAVE, h);
+      const double w = RAW(VIC_RAW_WIND, h);
+      wind += (w < a.min_wind) ? a.min_wind : w;                                      // :527-530
+    }
+    T /= a.snow_step; pr /= a.snow_step; vp /= a.snow_step; sw /= a.snow_step; lw /= a.snow_step; wind /= a.snow_step;
+    const double dens = a.plapse ? pr / (287.0 * (KELVIN + T)) : 0.003486 * pr / (275.0 + T);   // :988-998 (Rd = 287)
+    double vpd = svp(T) - vp;                                                         // :1179-1183
+    if (vpd < 0) { vpd = 0; vp = svp(T); }
+    F(VIC_F_AIR_TEMP, j) = T; F(VIC_F_PREC, j) = prec; F(VIC_F_PRESSURE, j) = pr; F(VIC_F_VP, j) = vp; F(VIC_F_VPD, j) = vpd;
+    F(VIC_F_DENSITY, j) = dens; F(VIC_F_SHORTWAVE, j) = sw; F(VIC_F_LONGWAVE, j) = lw; F(VIC_F_WIND, j) = wind;
+    const bool snow = ((T + min_Tfactor) < thr) && (prec > 0);                        // :1283-1300
+    sf[(size_t)j * nc] = snow ? 1 : 0;
+    any_snow = any_snow || snow;
+    sT += T; sP += prec; sPr += pr; sVp += vp; sVpd += vpd; sD += dens; sSw += sw; sLw += lw; sW += wind;
+  }
+  if (NF > 1) {                                                                       // x[NR] = sum / (float)NF; prec[NR] = sum
+    const double n = (double)(float)NF;
+    F(VIC_F_AIR_TEMP, a.NR) = sT / n; F(VIC_F_PREC, a.NR) = sP; F(VIC_F_PRESSURE, a.NR) = sPr / n; F(VIC_F_VP, a.NR) = sVp / n;
+    F(VIC_F_VPD, a.NR) = sVpd / n; F(VIC_F_DENSITY, a.NR) = sD / n; F(VIC_F_SHORTWAVE, a.NR) = sSw / n; F(VIC_F_LONGWAVE, a.NR) = sLw / n;
+    F(VIC_F_WIND, a.NR) = sW / n;
+    sf[(size_t)a.NR * nc] = any_snow ? 1 : 0;
+  }
+#undef RAW
+#undef F
+}
+
+static bool is_pinned(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { HIPIGN(hipGetLastError()); return false; }
+  return at.type == hipMemoryTypeHost;
+}
+
+// source -> device on the copy stream: straight from pinned memory, through the slot's staging area otherwise
+static hipError_t upload(vicgpu_ctx* c, vicgpu_ctx::ForcingSlot& sl, void* dst, const void* src, size_t bytes, size_t stage_off) {
+  const void* from = src;
+  if (!is_pinned(src)) {
+    memcpy((char*)sl.h_stage + stage_off, src, bytes);
+    from = (char*)sl.h_stage + stage_off;
+  }
+  return hipMemcpyAsync(dst, from, bytes, hipMemcpyHostToDevice, c->copy_stream);
+}
+
+static int prefetch_impl(vicgpu_ctx* c, int nsteps, const double* forcing, const unsigned char* snowflag, const double* raw,
+                         const int* dmy, double min_wind, int plapse) {
+  if (!c || nsteps <= 0 || !dmy || (!raw && (!forcing || !snowflag))) return VICGPU_ERR_ARG;
   if (!c->domain_ready) return VICGPU_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
-  const size_t nsub = c->o.NR + 1;
-  const size_t fbytes = sizeof(double) * (size_t)nsteps * VIC_NFORCE * nsub * c->ncell;
-  const size_t sbytes = (size_t)nsteps * nsub * c->ncell;
   for (int s = 0; s < nsteps; s++) {
     int m = dmy[(size_t)s * VIC_NDMY + VIC_DMY_MONTH];
     if (m < 1 || m > 12) return VICGPU_ERR_ARG;          // month indexes the veg library tables
   }
-  // the previous chunk may still be read by queued kernels
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (fbytes > c->forcing_cap) {
-    HIPIGN(hipFree(c->d_forcing)); c->d_forcing = nullptr;
-    HIPCHK(c, hipMalloc(&c->d_forcing, fbytes));
-    c->forcing_cap = fbytes;
+  const size_t nsub = c->o.NR + 1;
+  const size_t fbytes = sizeof(double) * (size_t)nsteps * VIC_NFORCE * nsub * c->ncell;
+  const size_t sbytes = (size_t)nsteps * nsub * c->ncell;
+  const size_t rbytes = raw ? sizeof(double) * (size_t)nsteps * VIC_NRAW * c->o.dt * c->ncell : 0;
+  const int t = (c->cur == 0) ? 1 : 0;
+  vicgpu_ctx::ForcingSlot& sl = c->slot[t];
+  // the slot's previous upload may still be reading its staging area; the steps that read the slot's device buffers were
+  // queued before `released` was recorded (vicgpu_swap_forcing): the copy stream waits for that, not the host
+  if (sl.upload_pending) { HIPCHK(c, hipEventSynchronize(sl.uploaded)); sl.upload_pending = false; }
+  if (sl.was_current) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, sl.released, 0));
+  const bool grow = fbytes > sl.fcap || sbytes > sl.scap || rbytes > sl.rawcap;
+  if (grow) {                                            // re-allocation: nothing may still use the old buffers
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    if (sl.was_current) HIPCHK(c, hipEventSynchronize(sl.released));
+    if (fbytes > sl.fcap) { HIPIGN(hipFree(sl.d_f)); sl.d_f = nullptr; sl.fcap = 0; HIPCHK(c, hipMalloc(&sl.d_f, fbytes)); sl.fcap = fbytes; }
+    if (sbytes > sl.scap) { HIPIGN(hipFree(sl.d_s)); sl.d_s = nullptr; sl.scap = 0; HIPCHK(c, hipMalloc(&sl.d_s, sbytes)); sl.scap = sbytes; }
+    if (rbytes > sl.rawcap) { HIPIGN(hipFree(sl.d_raw)); sl.d_raw = nullptr; sl.rawcap = 0; HIPCHK(c, hipMalloc(&sl.d_raw, rbytes)); sl.rawcap = rbytes; }
   }
-  if (sbytes > c->snowflag_cap) {
-    HIPIGN(hipFree(c->d_snowflag)); c->d_snowflag = nullptr;
-    HIPCHK(c, hipMalloc(&c->d_snowflag, sbytes));
-    c->snowflag_cap = sbytes;
+  const size_t need_stage = raw ? (is_pinned(raw) ? 0 : rbytes) : ((is_pinned(forcing) ? 0 : fbytes) + (is_pinned(snowflag) ? 0 : sbytes));
+  if (need_stage > sl.stage_cap) {
+    if (sl.h_stage) HIPIGN(hipHostFree(sl.h_stage));
+    sl.h_stage = nullptr; sl.stage_cap = 0;
+    HIPCHK(c, hipHostMalloc(&sl.h_stage, need_stage, hipHostMallocDefault));
+    sl.stage_cap = need_stage;
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_forcing, forcing, fbytes, hipMemcpyHostToDevice, c->copy_stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_snowflag, snowflag, sbytes, hipMemcpyHostToDevice, c->copy_stream));
-  HIPCHK(c, hipEventRecord(c->forcing_ready, c->copy_stream));
-  c->dmy.assign(dmy, dmy + (size_t)nsteps * VIC_NDMY);
-  c->chunk_steps = nsteps;
+  if (raw) {
+    HIPCHK(c, upload(c, sl, sl.d_raw, raw, rbytes, 0));
+    FArgs a;
+    a.nsteps = nsteps; a.ncell = c->ncell; a.dt = c->o.dt; a.snow_step = c->o.snow_step; a.NF = c->o.NF; a.NR = c->o.NR;
+    a.temp_th_type = c->o.TEMP_TH_TYPE; a.Nband = c->o.Nband; a.Nnode = c->o.Nnode; a.plapse = plapse; a.min_wind = min_wind;
+    a.raw = sl.d_raw; a.cell_params = c->d_cp; a.forcing = sl.d_f; a.snowflag = sl.d_s;
+    const size_t n = (size_t)nsteps * c->ncell;
+    hipLaunchKernelGGL(vic_derive_forcing, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->copy_stream, a);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    HIPCHK(c, upload(c, sl, sl.d_f, forcing, fbytes, 0));
+    HIPCHK(c, upload(c, sl, sl.d_s, snowflag, sbytes, is_pinned(forcing) ? 0 : fbytes));
+  }
+  HIPCHK(c, hipEventRecord(sl.uploaded, c->copy_stream));
+  sl.upload_pending = true;
+  sl.was_current = false;
+  sl.dmy.assign(dmy, dmy + (size_t)nsteps * VIC_NDMY);
+  sl.nsteps = nsteps;
+  c->staged = t;
   return VICGPU_OK;
 }
+
+int vicgpu_prefetch_forcing(vicgpu_ctx* c, int nsteps, const double* forcing, const unsigned char* snowflag, const int* dmy) {
+  return prefetch_impl(c, nsteps, forcing, snowflag, nullptr, dmy, 0.0, 1);
+}
+int vicgpu_prefetch_forcing_raw(vicgpu_ctx* c, int nsteps, const double* raw, const int* dmy, double min_wind_speed, int plapse) {
+  if (!raw) return VICGPU_ERR_ARG;
+  return prefetch_impl(c, nsteps, nullptr, nullptr, raw, dmy, min_wind_speed, plapse);
+}
+
+int vicgpu_swap_forcing(vicgpu_ctx* c) {
+  if (!c) return VICGPU_ERR_ARG;
+  if (c->staged < 0) return VICGPU_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->cur >= 0) {                                      // every step queued so far read the old chunk: fence it
+    HIPCHK(c, hipEventRecord(c->slot[c->cur].released, c->stream));
+    c->slot[c->cur].was_current = true;
+  }
+  vicgpu_ctx::ForcingSlot& sl = c->slot[c->staged];
+  // the source buffer (pinned user memory or the staging area) is free again once the upload has finished
+  HIPCHK(c, hipEventSynchronize(sl.uploaded));
+  sl.upload_pending = false;
+  c->cur = c->staged; c->staged = -1;
+  c->d_forcing = sl.d_f; c->d_snowflag = sl.d_s; c->dmy = sl.dmy; c->chunk_steps = sl.nsteps;
+  return VICGPU_OK;
+}
+
+int vicgpu_push_forcing(vicgpu_ctx* c, int nsteps, const double* forcing, const unsigned char* snowflag, const int* dmy) {
+  const int r = vicgpu_prefetch_forcing(c, nsteps, forcing, snowflag, dmy);
+  return r == VICGPU_OK ? vicgpu_swap_forcing(c) : r;
+}
+
+int vicgpu_get_forcing(vicgpu_ctx* c, int step, double* forcing, unsigned char* snowflag) {
+  if (!c || !forcing || !snowflag) return VICGPU_ERR_ARG;
+  if (c->cur < 0 || step < 0 || step >= c->chunk_steps) return VICGPU_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nsub = c->o.NR + 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, copy_on(c->stream, forcing, c->d_forcing + (size_t)step * VIC_NFORCE * nsub * c->ncell, sizeof(double) * VIC_NFORCE * nsub * c->ncell, hipMemcpyDeviceToHost));
+  HIPCHK(c, copy_on(c->stream, snowflag, c->d_snowflag + (size_t)step * nsub * c->ncell, nsub * c->ncell, hipMemcpyDeviceToHost));
+  return VICGPU_OK;
+}
+
+void* vicgpu_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void vicgpu_host_free(void* p) { if (p) HIPIGN(hipHostFree(p)); }
 
 int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   if (!c) return VICGPU_ERR_ARG;
   if (!c->domain_ready || !c->d_veglib || !c->d_forcing || c->chunk_steps <= 0) return VICGPU_ERR_STATE;
   if (step0 < 0 || nsteps <= 0 || step0 + nsteps > c->chunk_steps) return VICGPU_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamWaitEvent(c->stream, c->forcing_ready, 0));
   while ((int)c->ev.size() < 2 * nsteps) {
     hipEvent_t e;
     HIPCHK(c, hipEventCreate(&e));
