@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--node-solver", default="newton", choices=["newton", "brent"],
                     help="frozen-node root finder (vicgpu_options.NODE_SOLVER): converged Newton (default) or the reference's Brent iteration replayed")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timing with the other node solver (N = 1)")
+    ap.add_argument("--no-stream-leg", action="store_true", help="skip the PCIe-inclusive timing (forcing streamed in chunks, N = 1)")
     ap.add_argument("--ncell", type=int, default=0, help="override cells per GPU (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -299,6 +300,37 @@ def main():
         torch.cuda.synchronize()
         other_ms = (time.perf_counter() - ts) / K * 1e3
         m2.close()
+    # PCIe-inclusive rate (N = 1): the same K steps with the forcing arriving as hourly RAW values in chunks of 6 steps from
+    # pinned host memory, each chunk uploading (and derived on the device) while the previous one runs
+    stream_ms = None
+    if world == 1 and not args.no_stream_leg and opt.snow_step == 1:
+        m3 = Model(d, device=local_rank)
+        m3.set_state(sd0, si0); m3.set_write_fluxes(False); m3.put_data_config(OUT_STEP_RATIO); m3.put_data_init()
+        CH = 6
+        nch = max(1, K // CH)
+        bufs = [m3.pinned((CH, C["VIC_NRAW"], opt.dt, ncell)) for _ in range(2)]
+
+        def fill(buf, lo):
+            fs = f[lo:lo + CH]
+            for name, src, scale in (("VIC_RAW_AIR_TEMP", "VIC_F_AIR_TEMP", 1.0), ("VIC_RAW_PREC", "VIC_F_PREC", 1.0),
+                                     ("VIC_RAW_PRESSURE_KPA", "VIC_F_PRESSURE", 1e-3), ("VIC_RAW_VP_KPA", "VIC_F_VP", 1e-3),
+                                     ("VIC_RAW_SHORTWAVE", "VIC_F_SHORTWAVE", 1.0), ("VIC_RAW_LONGWAVE", "VIC_F_LONGWAVE", 1.0),
+                                     ("VIC_RAW_WIND", "VIC_F_WIND", 1.0)):
+                buf[:, C[name]] = fs[:, C[src], :opt.NF] * scale
+        fill(bufs[0], W)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        m3.prefetch_forcing_raw(bufs[0], dmy[W:W + CH]); m3.swap_forcing()
+        for k in range(nch):
+            if k + 1 < nch:
+                fill(bufs[(k + 1) % 2], W + (k + 1) * CH)           # the host prepares the next chunk ...
+                m3.prefetch_forcing_raw(bufs[(k + 1) % 2], dmy[W + (k + 1) * CH:W + (k + 2) * CH])   # ... and starts its upload
+            m3.dist_prec(0, CH, sync=False)
+            if k + 1 < nch:
+                m3.swap_forcing()
+        m3.synchronize()
+        stream_ms = (time.perf_counter() - ts) / (nch * CH) * 1e3
+        m3.close()
     del f
 
     if rank == 0:
@@ -318,6 +350,7 @@ def main():
                        "ranks_seen_by_rccl": ranks_seen if use_dist else None,
                        "node_solver": args.node_solver,
                        ("strict_replay_ms_per_step" if args.node_solver == "newton" else "newton_ms_per_step"): other_ms,
+                       "streamed_raw_forcing_ms_per_step": stream_ms,
                        "put_data": "on device every step (vic_put_data), out_step_ratio %d" % OUT_STEP_RATIO,
                        "output_table": "%s as float32 [%d][%d]" % (",".join(OUT_VARS), full.shape[0], full.shape[1]),
                        "cells_with_error_flags": nerr, "output_gather_ms": gather_ms,

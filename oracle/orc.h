@@ -170,6 +170,7 @@ typedef struct {
    * A test-only knob (vicorc_set_node_tolerance): tightened, the restatement converges those roots fully, which separates
    * the reference's own stopping error from implementation error when the product's Newton node solver is checked. */
   double node_macheps, node_ttol;
+  long implicit_ok, implicit_failed;   /* func_surf_energy_bal.c:198-202 error_cnt0 / error_cnt1 (test statistics; racy under OpenMP, only > 0 is asserted) */
 } orc_model;
 
 /* handle behind the vicorc_* entry points (orc_driver.c, orc_putdata.c) */

@@ -705,6 +705,8 @@ int vicorc_derive_forcing(void *hv, int nsteps, const double *raw, double min_wi
   return 0;
 }
 
+int vicorc_implicit_stats(void *hv, long *ok, long *failed) { vicorc_handle *h = (vicorc_handle *)hv; *ok = h->model.implicit_ok; *failed = h->model.implicit_failed; return 0; }
+
 static void export_flux(vicorc_handle *h, double *fx) {
   const size_t nh = h->nhru;
   int g, l, p;

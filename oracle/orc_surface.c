@@ -62,6 +62,172 @@ static void orc_node_freeze_params(const orc_model *m, const orc_soil *sc, int j
   } else { *mm = sc->max_moist_node[j]; *bub = sc->bubble_node[j]; *ex = sc->expt_node[j]; }
 }
 
+/* ------------------------------------------------------------------ IMPLICIT soil heat solution
+ * solve_T_profile_implicit (frozen_soil.c:229-301) with NewtonRaphsonMethod::{compute, fdjac3, fda_heat_eqn}
+ * (newt_raph_func_fast.c:17-170, frozen_soil.c:540-803) and tridiag (newt_raph_func_fast.c:173-219).
+ * Semantics of oracle patch P3: ice_new / Cs_new / kappa_new of fda_heat_eqn keep their values
+ * from call to call, as the `static` arrays of upstream VIC did.  Every Newton trial starts with a full evaluation that
+ * assigns kappa_new[0..n], ice_new[1..n], Cs_new[1..n], so arrays that live as long as one compute() are equivalent; the
+ * element kappa_new[n+1] the bottom node's Dkappa reads (!NOFLUX) is never assigned by anyone and keeps the 0 a static
+ * array starts with.  Node freezing parameters: the node arrays (P2; with frozen_compat the reference passes the 3-element
+ * layer arrays, frozen_soil.c:283-284 -- not reproduced for IMPLICIT). */
+typedef struct {
+  int n, NOFLUX, EXP_TRANS;
+  double deltat, Bexp, Ts, Tb;
+  const double *T0, *moist, *ice, *kappa, *Cs;
+  const orc_soil *sc;
+  double ice_new[VIC_MAX_NODES + 2], Cs_new[VIC_MAX_NODES + 2], kappa_new[VIC_MAX_NODES + 2];
+} orc_nr;
+
+static void orc_fda_heat_eqn(orc_nr *q, const double *T_2, double *res, int focus) {
+  const orc_soil *sc = q->sc;
+  const int n = q->n;
+  double DT[VIC_MAX_NODES], DT_down[VIC_MAX_NODES], DT_up[VIC_MAX_NODES], T_up[VIC_MAX_NODES], Dkappa[VIC_MAX_NODES];
+  double storage_term, flux_term, phase_term, flux_term1, flux_term2, Lsum;
+  int i, lidx, left, right, PAST_BOTTOM;
+  if (focus == -1) { left = 0; right = n - 1; }
+  else { left = (focus == 0) ? 0 : focus - 1; right = (focus == n - 1) ? n - 1 : focus + 1; }
+  if (focus == -1) {
+    lidx = 0; Lsum = 0.; PAST_BOTTOM = 0;
+    for (i = 0; i < n + 1; i++) {
+      q->kappa_new[i] = q->kappa[i];
+      if (i >= 1) {
+        if (T_2[i - 1] < 0) {
+          q->ice_new[i] = q->moist[i] - orc_maximum_unfrozen_water(T_2[i - 1], sc->max_moist_node[i], sc->bubble_node[i], sc->expt_node[i]);
+          if (q->ice_new[i] < 0) q->ice_new[i] = 0;
+        } else q->ice_new[i] = 0;
+        q->Cs_new[i] = q->Cs[i];
+        if (q->ice_new[i] != q->ice[i]) {
+          q->kappa_new[i] = orc_soil_conductivity(q->moist[i], q->moist[i] - q->ice_new[i], sc->soil_dens_min[lidx], sc->bulk_dens_min[lidx],
+                                                  sc->quartz[lidx], sc->soil_density[lidx], sc->bulk_density[lidx], sc->organic[lidx]);
+          q->Cs_new[i] = orc_volumetric_heat_capacity(sc->bulk_density[lidx] / sc->soil_density[lidx], q->moist[i] - q->ice_new[i],
+                                                      q->ice_new[i], sc->organic[lidx]);
+        }
+      }
+      if (sc->Zsum_node[i] > Lsum + sc->depth[lidx] && !PAST_BOTTOM) {
+        Lsum += sc->depth[lidx]; lidx++;
+        if (lidx == VIC_NLAYER) { PAST_BOTTOM = 1; lidx = VIC_NLAYER - 1; }
+      }
+    }
+  } else {
+    for (i = left; i <= right; i++) {
+      if (T_2[i] < 0) {
+        q->ice_new[i + 1] = q->moist[i + 1] - orc_maximum_unfrozen_water(T_2[i], sc->max_moist_node[i + 1], sc->bubble_node[i + 1], sc->expt_node[i + 1]);
+        if (q->ice_new[i + 1] < 0) q->ice_new[i + 1] = 0;
+      } else q->ice_new[i + 1] = 0;
+    }
+    lidx = 0; Lsum = 0.; PAST_BOTTOM = 0;
+    for (i = 0; i <= right + 1; i++) {
+      if (i >= left + 1 && q->ice_new[i] != q->ice[i]) {
+        q->kappa_new[i] = orc_soil_conductivity(q->moist[i], q->moist[i] - q->ice_new[i], sc->soil_dens_min[lidx], sc->bulk_dens_min[lidx],
+                                                sc->quartz[lidx], sc->soil_density[lidx], sc->bulk_density[lidx], sc->organic[lidx]);
+        q->Cs_new[i] = orc_volumetric_heat_capacity(sc->bulk_density[lidx] / sc->soil_density[lidx], q->moist[i] - q->ice_new[i],
+                                                    q->ice_new[i], sc->organic[lidx]);
+      }
+      if (sc->Zsum_node[i] > Lsum + sc->depth[lidx] && !PAST_BOTTOM) {
+        Lsum += sc->depth[lidx]; lidx++;
+        if (lidx == VIC_NLAYER) { PAST_BOTTOM = 1; lidx = VIC_NLAYER - 1; }
+      }
+    }
+  }
+  for (i = left; i <= right; i++) {
+    if (i == 0) { DT[i] = T_2[i + 1] - q->Ts; DT_up[i] = T_2[i] - q->Ts; DT_down[i] = T_2[i + 1] - T_2[i]; T_up[i] = q->Ts; }
+    else if (i == n - 1) { DT[i] = q->Tb - T_2[i - 1]; DT_up[i] = T_2[i] - T_2[i - 1]; DT_down[i] = q->Tb - T_2[i]; T_up[i] = T_2[i - 1]; }
+    else { DT[i] = T_2[i + 1] - T_2[i - 1]; DT_up[i] = T_2[i] - T_2[i - 1]; DT_down[i] = T_2[i + 1] - T_2[i]; T_up[i] = T_2[i - 1]; }
+    if (i < n - 1) Dkappa[i] = q->kappa_new[i + 2] - q->kappa_new[i];
+    else if (!q->NOFLUX) Dkappa[i] = q->kappa_new[i + 2] - q->kappa_new[i];
+    else Dkappa[i] = q->kappa_new[i + 1] - q->kappa_new[i];
+  }
+  for (i = left; i <= right; i++) {
+    storage_term = q->Cs_new[i + 1] * (T_2[i] - q->T0[i + 1]) / q->deltat + T_2[i] * (q->Cs_new[i + 1] - q->Cs[i + 1]) / q->deltat;
+    if (!q->EXP_TRANS) {
+      flux_term1 = Dkappa[i] / sc->alpha[i] * DT[i] / sc->alpha[i];
+      flux_term2 = q->kappa_new[i + 1] * (DT_down[i] / sc->gamma[i] - DT_up[i] / sc->beta[i]) / (0.5 * sc->alpha[i]);
+    } else {
+      const double z = sc->Zsum_node[i + 1] + 1.;
+      flux_term1 = Dkappa[i] / 2. * DT[i] / 2. / (q->Bexp * z) / (q->Bexp * z);
+      flux_term2 = q->kappa_new[i + 1] * ((DT_down[i] - DT_up[i]) / (q->Bexp * z) / (q->Bexp * z) - DT[i] / 2. / (q->Bexp * z * z));
+    }
+    /* "cold nose": every node in the full evaluation (the restriction is commented out there, frozen_soil.c:675),
+     * the two near-surface nodes in the focus evaluation (:783) */
+    if (focus == -1 || i == 0 || i == 1) {
+      if (fabs(DT[i]) > 5. && (T_2[i] < T_2[i + 1] && T_2[i] < T_up[i])) {
+        if ((flux_term1 < 0 && flux_term2 > 0) && fabs(flux_term1) > fabs(flux_term2)) flux_term1 = 0;
+      }
+    }
+    flux_term = flux_term1 + flux_term2;
+    phase_term = ORC_ICE_DENSITY * ORC_LF * (q->ice_new[i + 1] - q->ice[i + 1]) / q->deltat;
+    res[i] = flux_term + phase_term - storage_term;
+  }
+}
+
+static void orc_tridiag(double *a, double *b, double *c, double *r, int n) {      /* newt_raph_func_fast.c:173-219 */
+  int j;
+  double factor;
+  factor = b[0]; b[0] = 1.0; c[0] = c[0] / factor; r[0] = r[0] / factor;
+  for (j = 1; j < n; j++) {
+    factor = a[j]; a[j] = a[j] - b[j - 1] * factor; b[j] = b[j] - c[j - 1] * factor; r[j] = r[j] - r[j - 1] * factor;
+    factor = b[j]; b[j] = 1.0; c[j] = c[j] / factor; r[j] = r[j] / factor;
+  }
+  for (j = n - 2; j >= 0; j--) {
+    factor = c[j]; c[j] = c[j] - b[j + 1] * factor; r[j] = r[j] - r[j + 1] * factor;
+    factor = b[j]; r[j] = r[j] / factor;
+  }
+}
+
+/* returns 0, or 1 when the Newton iteration did not converge in 150 trials (the caller then solves explicitly) */
+static int orc_solve_T_profile_implicit(double *T, const double *T0, const double *kappa, const double *Cs, const double *moist,
+                                        double deltat, const double *ice, double Dp, int Nnodes, int NOFLUX, int EXP_TRANS,
+                                        const orc_soil *sc) {
+  enum { MAXTRIAL = 150 };
+  const double TOLX = 1e-4, TOLF = 1e-1, R_MAX = 2.0, R_MIN = -5.0, RELAX1 = 0.9, RELAX2 = 0.7, RELAX3 = 0.2, EPS2 = 1e-4;
+  const int n = NOFLUX ? Nnodes - 1 : Nnodes - 2;
+  double *x = &T[1];
+  double fvec[VIC_MAX_NODES], f[VIC_MAX_NODES], p[VIC_MAX_NODES], a[VIC_MAX_NODES], b[VIC_MAX_NODES], c[VIC_MAX_NODES];
+  orc_nr q;
+  int i, j, k;
+  memset(&q, 0, sizeof(q));
+  q.n = n; q.NOFLUX = NOFLUX; q.EXP_TRANS = EXP_TRANS; q.deltat = deltat; q.T0 = T0; q.moist = moist; q.ice = ice; q.kappa = kappa;
+  q.Cs = Cs; q.sc = sc;
+  if (EXP_TRANS) q.Bexp = NOFLUX ? log(Dp + 1.) / (double)n : log(Dp + 1.) / (double)(n + 1);
+  q.Ts = T0[0];
+  q.Tb = NOFLUX ? T0[n] : T0[n + 1];
+  for (i = 0; i < n; i++) x[i] = T0[i + 1];
+  for (k = 0; k < MAXTRIAL; k++) {
+    double errf = 0.0, errx = 0.0;
+    orc_fda_heat_eqn(&q, x, fvec, -1);
+    for (i = 0; i < n; i++) errf += fabs(fvec[i]);
+    if (errf <= TOLF) goto converged;
+    for (j = 0; j < n; j++) {                                                       /* fdjac3, newt_raph_func_fast.c:136-167 */
+      const double temp = x[j];
+      double h = EPS2 * fabs(temp);
+      if (h == 0) h = EPS2;
+      x[j] = temp + h;
+      h = x[j] - temp;
+      orc_fda_heat_eqn(&q, x, f, j);
+      x[j] = temp;
+      b[j] = (f[j] - fvec[j]) / h;
+      if (j != 0) c[j - 1] = (f[j - 1] - fvec[j - 1]) / h;
+      if (j != n - 1) a[j + 1] = (f[j + 1] - fvec[j + 1]) / h;
+    }
+    for (i = 0; i < n; i++) p[i] = -fvec[i];
+    orc_tridiag(a, b, c, p, n);
+    for (i = 0; i < n; i++) {
+      errx += fabs(p[i]);
+      if (k > 10 && k <= 20 && x[i] < R_MAX && x[i] > R_MIN) x[i] += p[i] * RELAX1;
+      else if (k > 20 && k <= 60 && x[i] < R_MAX && x[i] > R_MIN) x[i] += p[i] * RELAX2;
+      else if (k > 60 && x[i] < R_MAX && x[i] > R_MIN) x[i] += p[i] * RELAX3;
+      else x[i] += p[i];
+    }
+    if (errx <= TOLX) goto converged;
+  }
+  return 1;
+converged:
+  T[0] = T0[0];
+  if (!NOFLUX) T[Nnodes - 1] = T0[Nnodes - 1];
+  return 0;
+}
+
 /* solve_T_profile (frozen_soil.c:105-225) + calc_soil_thermal_fluxes (:305-505); the A-E coefficients are recomputed
  * on every call, which is what the upstream `static` arrays give (SURVEY.md Finding 1.1). */
 static int orc_solve_T_profile(const orc_model *m, double *T, const double *T0, int *Tfbflag, int *Tfbcount,
@@ -224,11 +390,19 @@ static double orc_surf_energy_bal(double Ts, void *vctx) {
                       * (c->kappa1 / c->D1 * ((*c->T1) - TMean)
                          + (c->kappa2 / c->D2 * (1. - exp(-c->D1 / c->dp)) * (c->T2 - (*c->T1)))) / 2.;
   } else {
-    int err;
+    int err = 1;
     c->T_node[0] = TMean;
-    err = orc_solve_T_profile(m, c->Tnew_node, c->T_node, c->Tnew_fbflag, c->Tnew_fbcount, c->kappa_node, c->Cs_node,
-                              c->moist_node, c->delta_t, c->ice_node, c->dp, c->Nnodes, c->NOFLUX, c->EXP_TRANS, sc);
-    if (err) return ORC_ERROR;
+    if (m->opt.IMPLICIT)                                                            /* func_surf_energy_bal.c:192-210 */
+    {
+      err = orc_solve_T_profile_implicit(c->Tnew_node, c->T_node, c->kappa_node, c->Cs_node, c->moist_node, c->delta_t, c->ice_node,
+                                         c->dp, c->Nnodes, c->NOFLUX, c->EXP_TRANS, sc);
+      if (err == 0) ((orc_model *)m)->implicit_ok++; else ((orc_model *)m)->implicit_failed++;
+    }
+    if (!m->opt.IMPLICIT || err == 1) {                                             /* explicit, or the implicit solution failed (:212-222) */
+      err = orc_solve_T_profile(m, c->Tnew_node, c->T_node, c->Tnew_fbflag, c->Tnew_fbcount, c->kappa_node, c->Cs_node,
+                                c->moist_node, c->delta_t, c->ice_node, c->dp, c->Nnodes, c->NOFLUX, c->EXP_TRANS, sc);
+      if (err) return ORC_ERROR;
+    }
     *c->T1 = c->Tnew_node[1];
     if (m->opt.GRND_FLUX_TYPE == VIC_GF_406)
       *c->grnd_flux = (c->snow_coverage + (1. - c->snow_coverage) * c->surf_atten) * (c->kappa1 / c->D1 * ((*c->T1) - TMean));
@@ -316,7 +490,7 @@ static double orc_surf_energy_bal(double Ts, void *vctx) {
   return error;
 }
 
-/* calc_surf_energy_bal.c:7-692 (QUICK_SOLVE / IMPLICIT not supported).  Returns Tsurf or ORC_ERROR. */
+/* calc_surf_energy_bal.c:7-692 (QUICK_SOLVE not supported).  Returns Tsurf or ORC_ERROR. */
 double orc_calc_surf_energy_bal(const orc_model *m, double Le, double LongUnderIn, double NetLongSnow, double NetShortGrnd,
                                 double NetShortSnow, double OldTSurf, double ShortUnderIn, double SnowAlbedo,
                                 double SnowLatent, double SnowLatentSub, double SnowSensible, double Tair, double VPDcanopy,

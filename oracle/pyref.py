@@ -229,6 +229,14 @@ class OracleModel(_Model):
         assert fn(self.h, raw.shape[0], _d(raw), float(min_wind), int(plapse), _d(f), sf.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte))) == 0
         return f, sf
 
+    def implicit_stats(self):
+        """(converged, failed) calls of the implicit soil heat solver so far."""
+        ok, bad = ctypes.c_long(0), ctypes.c_long(0)
+        f = self.lib.vicorc_implicit_stats; f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
+        f(self.h, ctypes.byref(ok), ctypes.byref(bad))
+        return ok.value, bad.value
+
     def get_state_records(self):
         from vic_amd import abi
         rec = np.zeros((self.dom.nhru, abi.sr_len(self.dom.opt.Nnode)))

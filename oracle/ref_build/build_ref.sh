@@ -2,7 +2,9 @@
 # build_ref.sh — TEST INFRASTRUCTURE.  Builds the real reference's hot path into
 #   oracle/_ref/libvicref.so         unmodified sources (valid for QUICK_FLUX configs)
 #   oracle/_ref/libvicref_compat.so  + P1 (frozen_soil.c:150-154 coefficient arrays made static thread_local)
-#   oracle/_ref/libvicref_fixed.so   + P1 + P2 (node arrays passed at frozen_soil.c:218-221)
+#   oracle/_ref/libvicref_fixed.so   + P1 + P2 (node arrays passed at frozen_soil.c:218-221 and :283-284) + P3 (the
+#                                    ice_new/Cs_new/kappa_new arrays of fda_heat_eqn, frozen_soil.c:567, static thread_local:
+#                                    the IMPLICIT residual reads elements only an earlier call assigned)
 # from the sources where they lie under /root/reference.  Nothing from the reference is copied into
 # this repository: the scratch directory (mktemp, outside the repo, removed at exit) holds SYMLINKS to
 # the reference files plus three generated files:
@@ -47,6 +49,13 @@ sed -E 's/^  double ([ABCDE])\[MAX_NODES\];/  static thread_local double \1[MAX_
 [ "$(grep -c 'static thread_local double [ABCDE]\[MAX_NODES\]' fs_compat.cpp)" = 5 ]
 sed 's/soil_con->max_moist, ice, soil_con->bubble, soil_con->expt, soil_con->alpha/soil_con->max_moist_node, ice, soil_con->bubble_node, soil_con->expt_node, soil_con->alpha/' fs_compat.cpp > fs_fixed.cpp
 [ "$(grep -c 'soil_con->max_moist_node, ice, soil_con->bubble_node' fs_fixed.cpp)" = 1 ]
+# P2 for the implicit solver's constructor call (frozen_soil.c:282-284) and P3
+sed -i -e 's/NOFLUX, EXP_TRANS, T0, moist, ice, kappa, Cs, soil_con->max_moist,/NOFLUX, EXP_TRANS, T0, moist, ice, kappa, Cs, soil_con->max_moist_node,/' \
+       -e 's/^      soil_con->bubble, soil_con->expt, soil_con->alpha, soil_con->beta,/      soil_con->bubble_node, soil_con->expt_node, soil_con->alpha, soil_con->beta,/' \
+       -e 's/^  double ice_new\[MAX_NODES\], Cs_new\[MAX_NODES\], kappa_new\[MAX_NODES\];/  static thread_local double ice_new[MAX_NODES], Cs_new[MAX_NODES], kappa_new[MAX_NODES];/' fs_fixed.cpp
+[ "$(grep -c 'Cs, soil_con->max_moist_node,' fs_fixed.cpp)" = 1 ]
+[ "$(grep -c 'soil_con->bubble_node, soil_con->expt_node, soil_con->alpha, soil_con->beta,' fs_fixed.cpp)" = 1 ]
+[ "$(grep -c 'static thread_local double ice_new' fs_fixed.cpp)" = 1 ]
 g++ $CXXFLAGS -c fs_compat.cpp -o fs_compat.o
 g++ $CXXFLAGS -c fs_fixed.cpp -o fs_fixed.o
 g++ $CXXFLAGS -c "$HERE/vicref_shim.cpp" -o shim.o

@@ -50,10 +50,23 @@ OPTION_BRANCHES = {
                                     nsteps=100, doy=100, tweak="zero_area_glacier"),
 }
 
+# IMPLICIT soil heat solution (newt_raph_func_fast.c, frozen_soil.c:229-301,540-803): Newton iteration with the explicit
+# solver as its fallback.  "fixed" reference variant = P1 + P2 + P3 (oracle/ref_build/build_ref.sh).
+IMPLICIT_BRANCHES = {
+    # Order matters in one process: the patched reference keeps fda_heat_eqn's work arrays in thread-local statics, and the
+    # bottom node reads kappa_new[n + 1], which nothing ever assigns -- 0 in any real run (n is fixed), but a left-over of an
+    # earlier, larger n in a test process.  So the node count never decreases along this list.
+    "implicit": dict(kw=dict(FROZEN, IMPLICIT=1), variant="fixed", ncell=4, ntile=2, nsteps=150, doy=330),
+    "implicit_spring": dict(kw=dict(FROZEN, IMPLICIT=1), variant="fixed", ncell=4, ntile=3, nsteps=120, doy=95),
+    "implicit_exp_trans": dict(kw=dict(FROZEN, IMPLICIT=1, EXP_TRANS=1), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=330),
+    "implicit_glacier": dict(kw=dict(FROZEN, IMPLICIT=1, Nband=2), variant="fixed", ncell=4, ntile=2, glacier=True, nsteps=80, doy=100),
+    "implicit_noflux_n12": dict(kw=dict(FROZEN, IMPLICIT=1, NOFLUX=1, Nnode=12), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=10),
+}
+
 
 def build(name, nsteps=None):
     """Domain + forcing of a scenario: returns (spec, d, f, sf, dmy)."""
-    sp = OPTION_BRANCHES[name]
+    sp = OPTION_BRANCHES[name] if name in OPTION_BRANCHES else IMPLICIT_BRANCHES[name]
     opt = abi.default_options(**sp["kw"])
     d = domain.make_domain(sp["ncell"], opt, ntile=sp["ntile"], glacier_top_band=sp.get("glacier", False))
     n = nsteps or sp["nsteps"]

@@ -93,7 +93,10 @@ def test_oracle_vs_reference_side_by_side(case, oracle_lib, ref_available):
     ref.close()
 
 
-@pytest.mark.parametrize("name", list(__import__("tests.scenarios", fromlist=["x"]).OPTION_BRANCHES))
+_SC = __import__("tests.scenarios", fromlist=["x"])
+
+
+@pytest.mark.parametrize("name", list(_SC.OPTION_BRANCHES) + list(_SC.IMPLICIT_BRANCHES))
 def test_oracle_vs_reference_option_branches(name, oracle_lib, ref_available):
     """Every run-time option branch of the path (tests/scenarios.py: EXP_TRANS, NOFLUX, node counts, GRND_FLUX_TYPE,
     AERO_RESIST_CANSNOW, SNTHERM / SUN1999 / VIC_412, TFALLBACK off, forced solver failures, GLACIER_DYNAMICS): the oracle
@@ -135,6 +138,10 @@ def test_oracle_vs_reference_option_branches(name, oracle_lib, ref_available):
         nfb += int(io[C["SI_TSURF_FBFLAG"]].sum())
     if sp.get("expect_errors"):
         assert nerr > 0, "the stress forcing did not make any solver fail"
+    if sp["kw"].get("IMPLICIT"):
+        ok, failed = orc.implicit_stats()
+        print(name, "implicit solver: %d converged, %d fell back to the explicit one" % (ok, failed))
+        assert ok > 0
     if sp.get("tweak") == "stress" and not sp.get("expect_errors"):
         assert nfb > 0, "the stress forcing did not trigger a single Tsurf fallback"
     ref.close()

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/round
 rm -rf $O && mkdir -p $O
-ARGS=${BENCH_ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-strict-leg}
+ARGS=${BENCH_ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-strict-leg --no-stream-leg}
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 $R/bench.py $ARGS > $O/bench_trace.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $R/bench.py $ARGS > $O/bench_fetch.log 2>&1 || exit 1
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python3 $R/bench.py $ARGS > $O/bench_write.log 2>&1 || exit 1
