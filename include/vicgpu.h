@@ -23,10 +23,11 @@
  * Option coverage: Nlayer = 3, DIST_PRCP = FALSE
  * (Ndist = 1, mu = 1), no lakes, no EXCESS_ICE / SPATIAL_FROST / SPATIAL_SNOW /
  * QUICK_FS / LOW_RES_MOIST / CLOSE_ENERGY (all compiled out in the reference,
- * user_def.h:36-92).  CORRPREC is implemented.  The options struct carries IMPLICIT,
- * BLOWING and QUICK_SOLVE so that a binding passes the reference's settings through
- * unchanged: what the device code does not implement (see vicgpu_create) is REJECTED
- * with VICGPU_ERR_UNSUPPORTED, never silently replaced by another solver.
+ * user_def.h:36-92).  CORRPREC and IMPLICIT (finite-difference soil profile, node-array
+ * freezing parameters: frozen_compat = 0) are implemented.  The options struct also
+ * carries BLOWING and QUICK_SOLVE so that a binding passes the reference's settings
+ * through unchanged: what the device code does not implement (see vicgpu_create) is
+ * REJECTED with VICGPU_ERR_UNSUPPORTED, never silently replaced by another solver.
  */
 #ifndef VICGPU_H_
 #define VICGPU_H_
@@ -97,7 +98,8 @@ typedef struct vicgpu_options {
                                SURVEY.md Finding 1.2); 0 = node arrays ("fixed") */
   int nveg_types;           /* veg_lib[0].NVegLibTypes; the table holds nveg_types + 4 rows */
   int CORRPREC;             /* gauge-undercatch correction of precipitation (correct_precip.c, full_energy.c:188-194) */
-  int IMPLICIT;             /* options.IMPLICIT: Newton-Raphson soil heat solver (frozen_soil.c:229-301, newt_raph_func_fast.c) */
+  int IMPLICIT;             /* options.IMPLICIT: Newton-Raphson soil heat solver (frozen_soil.c:229-301, newt_raph_func_fast.c),
+                               the explicit solver as its fallback; rejected with QUICK_FLUX or frozen_compat */
   int BLOWING;              /* options.BLOWING: blowing-snow sublimation (CalcBlowingSnow.c); rejected when set */
   int QUICK_SOLVE;          /* options.QUICK_SOLVE (calc_surf_energy_bal.c:289-314, 400-475); rejected when set */
   int NODE_SOLVER;          /* VIC_NODE_SOLVER_*: how the frozen-node heat balance (soil_thermal_eqn.c) is solved -- not a

@@ -70,6 +70,7 @@ CASES = {
 #           the reference's own noise, not a property of its equations.  So this mode is checked against the oracle with
 #           ITS node root finds converged as well (OracleModel(converged_nodes=True), same algorithm, node tolerance 1e-13 K)
 #           at the same 1e-6, and against the unmodified oracle / reference data on the outputs north_star names at 1e-5.
+IMPLICIT_TOL, IMPLICIT_FLOOR = 1e-3, 1e-2
 SOLVERS = {"brent": C["VIC_NODE_SOLVER_BRENT"], "newton": C["VIC_NODE_SOLVER_NEWTON"]}
 
 
@@ -141,12 +142,14 @@ def assert_int_state_equal(io, ig, Nn, where):
             where, len(bad), names.get(int(r), "node row "), "" if int(r) in names else int(r) - C["SI_NSCALAR"], c, io[r, c], ig[r, c]))
 
 
-@pytest.mark.parametrize("name,solver", _with_solvers([(n, sp["kw"]) for n, sp in scenarios.OPTION_BRANCHES.items()]))
+@pytest.mark.parametrize("name,solver", _with_solvers([(n, sp["kw"]) for n, sp in list(scenarios.OPTION_BRANCHES.items())
+                                                       + list(scenarios.IMPLICIT_BRANCHES.items())]))
 def test_teacher_forced_option_branches(name, solver, oracle_lib):
     """One case per run-time option branch of the device code (tests/scenarios.py; each is pinned oracle-vs-reference in
     tests/test_oracle.py): EXP_TRANS, NOFLUX, node counts 5/12/18 on the generic template, GRND_FLUX_TYPE, every
     AERO_RESIST_CANSNOW variant, SNTHERM, SUN1999, VIC_412, TFALLBACK off, forced solver failures (fallback flags and
-    counters with TFALLBACK on, per-cell error bits with it off), GLACIER_DYNAMICS with zero-area glacier HRUs."""
+    counters with TFALLBACK on, per-cell error bits with it off), GLACIER_DYNAMICS with zero-area glacier HRUs, and the
+    IMPLICIT soil heat solution (Newton iteration, explicit solver as its fallback)."""
     from vic_amd.api import Model
     sp, d, f, sf, dmy = scenarios.build(name, nsteps=36)
     d.opt.NODE_SOLVER = SOLVERS[solver]
@@ -183,15 +186,27 @@ def test_teacher_forced_option_branches(name, solver, oracle_lib):
         so, sg, io, ig = so[:, okh], sg[:, okh], io[:, okh], ig[:, okh]
         assert np.nanmax(np.abs(so[C["SD_ERROR"]] - sg[C["SD_ERROR"]])) < 1e-3
         so[C["SD_ERROR"]] = 0; sg[C["SD_ERROR"]] = 0
-        w1, m1 = worst(so, sg, "SD_", floor=1e-6)
+        # IMPLICIT: the reference's Newton iteration amplifies a 1-ulp change of its inputs to ~1e-6 K in the node temperatures
+        # (exact comparisons `ice_new != ice` choose between kept and recomputed conductivities; tests/test_oracle.py::
+        # test_implicit_solution_is_ulp_sensitive measures it on the oracle itself), so the bound is that spread, not 1e-6 relative
+        tol, floor = (IMPLICIT_TOL, IMPLICIT_FLOOR) if d.opt.IMPLICIT else (TF_TOL, 1e-6)
+        w1, m1 = worst(so, sg, "SD_", floor=floor)
         rows = FLUX_ROWS_COMMON + (GLACIER_ROWS if sp.get("glacier") else [])
         act = active_hrus(d, glacier_dynamics=bool(d.opt.GLACIER_DYNAMICS)) & okh
-        w2, m2 = worst(fo[rows][:, act], fg[rows][:, act], "FX_", floor=1e-6)
-        w3, m3 = worst(co[:, eo == 0], cg[:, eo == 0], "CO_", floor=1e-6)
-        assert w1 < TF_TOL, "step %d state %s" % (s, m1)
-        assert w2 < TF_TOL, "step %d flux %s" % (s, m2)
-        assert w3 < TF_TOL, "step %d cell %s" % (s, m3)
-        assert_int_state_equal(io, ig, d.opt.Nnode, "step %d" % s)
+        w2, m2 = worst(fo[rows][:, act], fg[rows][:, act], "FX_", floor=floor)
+        w3, m3 = worst(co[:, eo == 0], cg[:, eo == 0], "CO_", floor=floor)
+        assert w1 < tol, "step %d state %s" % (s, m1)
+        assert w2 < tol, "step %d flux %s" % (s, m2)
+        assert w3 < tol, "step %d cell %s" % (s, m3)
+        if not d.opt.IMPLICIT:
+            assert_int_state_equal(io, ig, d.opt.Nnode, "step %d" % s)
+        else:
+            snow_rows = [C[r] for r in ("SI_SNOW_LAST_SNOW", "SI_SNOW_MELTING", "SI_SNOW_SNOW", "SI_SNOW_STORE_SNOW")]
+            assert np.array_equal(io[snow_rows], ig[snow_rows]), "step %d snow flags" % s
+            # the outputs north_star names keep its 1e-5
+            w4, m4 = worst(so[HEADLINE_STATE_ROWS], sg[HEADLINE_STATE_ROWS], "SD_", floor=1e-4)
+            w5, m5 = worst(fo[HEADLINE_FLUX_ROWS][:, act], fg[HEADLINE_FLUX_ROWS][:, act], "FX_", floor=1e-4)
+            assert max(w4, w5) < 1e-5, "step %d headline outputs %s / %s" % (s, m4, m5)
         nfb += int(io[C["SI_TSURF_FBFLAG"]].sum())
         worst_all = max(worst_all, w1, w2, w3)
     if sp.get("expect_errors"):

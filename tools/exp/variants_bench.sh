@@ -1,12 +1,15 @@
 #!/bin/bash
-for so in tools/exp/variants/*.so; do
-  VICGPU_LIB=$PWD/$so timeout -k 10 300 python bench.py --steps 16 --warmup 4 --no-cpu-baseline > gpurun_out/vbench_$(basename $so .so).json 2> gpurun_out/vbench_$(basename $so .so).err
-  python - <<PY
+for so in vic_amd/libvicgpu.so tools/exp/variants/*.so; do
+  n=$(basename $so .so)
+  for cfg in cfg3 cfg2; do
+    VICGPU_LIB=$PWD/$so timeout -k 10 300 python bench.py --config $cfg --steps 12 --warmup 4 --no-cpu-baseline --no-strict-leg --no-stream-leg > gpurun_out/vbench_${n}_$cfg.json 2> gpurun_out/vbench_${n}_$cfg.err
+    python - <<PY
 import json
 try:
-    j = json.load(open("gpurun_out/vbench_$(basename $so .so).json"))
-    print("$so", "ms/step %.2f" % j["ms_per_step"], "strict %.2f" % (j["config"].get("strict_replay_ms_per_step") or 0))
+    j = json.load(open("gpurun_out/vbench_${n}_$cfg.json"))
+    print("$so $cfg", "ms/step %.3f" % j["ms_per_step"])
 except Exception as e:
-    print("$so failed", e)
+    print("$so $cfg failed", e)
 PY
+  done
 done

@@ -81,6 +81,8 @@ struct KArgs {
   int* count;                       // [NBUCKET]
   int list_cap;
   int* hkey;                        // [nhru] work-list segment of each HRU (number of frozen nodes)
+  double* pimp;                     // IMPLICIT: the implicit solver's item blocks [nhru][Nn][PIMP]
+  int* lastexp;                     // IMPLICIT: [nhru] record slot holding the flags of the root find's last explicit solve
   int phase;                        // 0: start of the step; p >= 1: after the root finder of sub-step p - 1
 };
 
@@ -164,6 +166,8 @@ VIC_DEV void list_append(int* __restrict__ list, int* count, int cap, bool pred,
   base = __shfl(base, pred ? __ffsll((long long)mine) - 1 : lane);
   if (pred) list[(size_t)key * cap + base + rank] = g;
 }
+
+#include "vic_implicit.hpp"
 
 // ------------------------------------------------------------------------------------------------ state table I/O
 // node_props = false leaves the node moisture / ice / conductivity / heat-capacity rows for load_node_props
@@ -667,6 +671,16 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
         a.hkey[g] = key;
       }
       profile_item_store<NN>(o, cv, s3, w.nd, eb.delta_t, eb.frozen_on != 0, a.pin + (size_t)g * Nn * PREC);
+      if (o.IMPLICIT) {
+        double* __restrict__ im = a.pimp + (size_t)g * Nn * PIMP;
+#pragma unroll
+        for (int n = 0; n < NN; n++)
+          if (n < Nn) {
+            im[n * PIMP + PI_MOIST] = w.nd.moist[n]; im[n * PIMP + PI_ICE] = (n == 0) ? eb.delta_t : w.nd.ice[n];
+            im[n * PIMP + PI_KAPPA] = w.nd.kappa[n]; im[n * PIMP + PI_CS] = w.nd.Cs[n];
+          }
+        a.lastexp[g] = -1;
+      }
       a.ts[g] = sv.x;
       a.pslot[g] = 0;
       a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 0)] = NAN;      // no solve on record yet
@@ -709,6 +723,7 @@ struct EArgs {
   const int* hkey;
   int* profile_next;     // work-list cursor of the profile kernel, cleared for its next launch
   int* evalonly;         // HRUs that wait for an evaluation without a solve (final evaluation on record)
+  int implicit;          // IMPLICIT: the final evaluation is always solved again (its fallback flags depend on the solves before it)
 };
 
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const EArgs a) {
@@ -736,7 +751,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
   surf_solve_consume(a.o, sv, eb, fx);
   bool need_solve = sv.stage != SurfSolve::DONE;
-  if (sv.stage == SurfSolve::FINAL) {
+  if (sv.stage == SurfSolve::FINAL && !a.implicit) {
     // the root has been found: the final evaluation needs the profile at sv.x, which is on record if sv.x is one of the
     // last two trial points; the evaluation itself happens in the next round, together with everybody else's (making it
     // here, in a second pass over eval(), costs the kernel 548 B of scratch per lane and 5 ms per step: measured, dropped)
@@ -1004,6 +1019,7 @@ struct FdChunk {
   int* d_glist = nullptr;          // their HRUs, ascending
   int gcount = 0;
   int* d_list[2] = {nullptr, nullptr};   // work lists (HRU ids)
+  int *d_fb_list = nullptr, *d_fb_count = nullptr;   // IMPLICIT: HRUs whose Newton iteration failed this round
   int* d_count = nullptr;          // [l * NBUCKET + b] segment sizes of list l, then CNT_CURSOR, CNT_EVALONLY
   int list_cap = 0;                // entries per segment
   int* h_count = nullptr;          // pinned read-back, two slots of CNT_TOTAL
@@ -1053,7 +1069,8 @@ struct vicgpu_ctx {
   bool fd = false;
   unsigned long long* d_ctx = nullptr;
   double *d_pin = nullptr, *d_ts = nullptr, *d_pout = nullptr;
-  int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr;
+  int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr, *d_lastexp = nullptr;
+  double* d_pimp = nullptr;        // IMPLICIT only
   int profile_waves = 0;           // resident waves of the profile kernel
   bool node_newton = false;        // frozen-node root finder: safeguarded Newton instead of the reference's Brent iteration
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
@@ -1069,13 +1086,15 @@ struct vicgpu_ctx {
 static void free_domain(vicgpu_ctx* c) {
   void* ps[] = {c->d_cp, c->d_hpd, c->d_sd, c->d_flux, c->d_cell_out, c->d_accum, c->d_hpi, c->d_si, c->d_cell_off, c->d_cell_list,
                 c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_pslot, c->d_hkey,
-                c->d_out_data, c->d_out_agg, c->d_pb, c->d_rowagg};
+                c->d_out_data, c->d_out_agg, c->d_pb, c->d_rowagg, c->d_pimp, c->d_lastexp};
   for (void* p : ps) HIPIGN(hipFree(p));
   c->d_out_data = c->d_out_agg = c->d_pb = nullptr;
   c->d_rowagg = nullptr;
+  c->d_pimp = nullptr; c->d_lastexp = nullptr;
   c->put_on = false;
   for (FdChunk& ch : c->chunks) {
     HIPIGN(hipFree(ch.d_glist)); HIPIGN(hipFree(ch.d_list[0])); HIPIGN(hipFree(ch.d_list[1])); HIPIGN(hipFree(ch.d_count));
+    HIPIGN(hipFree(ch.d_fb_list)); HIPIGN(hipFree(ch.d_fb_count));
     if (ch.h_count) HIPIGN(hipHostFree(ch.h_count));
     if (ch.done) HIPIGN(hipEventDestroy(ch.done));
     for (hipEvent_t e : ch.readback) if (e) HIPIGN(hipEventDestroy(e));
@@ -1184,7 +1203,7 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
   ea.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
   ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + CNT_CURSOR; ea.evalonly = ch->d_count + CNT_EVALONLY;
-  ea.list_cap = ch->list_cap; ea.hkey = c->d_hkey;
+  ea.list_cap = ch->list_cap; ea.hkey = c->d_hkey; ea.implicit = c->o.IMPLICIT;
   const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
@@ -1193,6 +1212,17 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
     for (int round = 0;; round++) {
       pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur * NBUCKET; pa.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
       pa.evalonly_zero = ch->d_count + CNT_EVALONLY;
+      if (c->o.IMPLICIT) {
+        // the Newton iteration for every listed HRU; those it fails for go on the fall-back list, which the explicit kernel
+        // (the same one, on that list) solves right after (func_surf_energy_bal.c:192-222)
+        CHKCH(ch, hipMemsetAsync(ch->d_fb_count, 0, sizeof(int) * NBUCKET, st));
+        IArgs ia;
+        ia.ncell = c->ncell; ia.nhru = c->nhru; ia.Nband = c->o.Nband; ia.pimp = c->d_pimp; ia.hpi = c->d_hpi; ia.cell_params = c->d_cp;
+        ia.hkey = c->d_hkey; ia.fb_list = ch->d_fb_list; ia.fb_count = ch->d_fb_count; ia.lastexp = c->d_lastexp;
+        hipLaunchKernelGGL(vic_profile_solve_implicit, dim3((nmax + 63) / 64 > 0 ? (nmax + 63) / 64 : 1), dim3(64), 0, st, pa, ia);
+        CHKCH(ch, hipGetLastError());
+        pa.list = ch->d_fb_list; pa.count = ch->d_fb_count;
+      }
       CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, c->node_newton, st)
                      : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, c->node_newton, st)));
       ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1) * NBUCKET;
@@ -1326,7 +1356,10 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   if (opt->QUICK_FLUX && opt->Nnode != 3) return VICGPU_ERR_ARG;             // get_global_param.c:1151-1155
   if (opt->FROZEN_SOIL && opt->QUICK_FLUX) return VICGPU_ERR_ARG;            // get_global_param.c:376-381
   // options of the reference this library does not implement are refused, never silently replaced
-  if (opt->BLOWING || opt->QUICK_SOLVE || opt->IMPLICIT) return VICGPU_ERR_UNSUPPORTED;
+  if (opt->BLOWING || opt->QUICK_SOLVE) return VICGPU_ERR_UNSUPPORTED;
+  // IMPLICIT (newt_raph_func_fast.c): the finite-difference soil profile with the node freezing parameters of the node
+  // arrays; the reference as shipped reads the 3-element layer arrays out of bounds there (frozen_soil.c:283-284)
+  if (opt->IMPLICIT && (opt->QUICK_FLUX || opt->frozen_compat)) return VICGPU_ERR_UNSUPPORTED;
   if (opt->NODE_SOLVER != VIC_NODE_SOLVER_BRENT && opt->NODE_SOLVER != VIC_NODE_SOLVER_NEWTON) return VICGPU_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VICGPU_ERR_HIP;   // no CPU fallback: fail loudly
@@ -1342,6 +1375,7 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   o.AERO_RESIST_CANSNOW = opt->AERO_RESIST_CANSNOW; o.SNOW_ALBEDO = opt->SNOW_ALBEDO; o.SNOW_DENSITY = opt->SNOW_DENSITY;
   o.TEMP_TH_TYPE = opt->TEMP_TH_TYPE; o.GLACIER_ID = opt->GLACIER_ID; o.GLACIER_DYNAMICS = opt->GLACIER_DYNAMICS;
   o.frozen_compat = opt->frozen_compat; o.nveg_types = opt->nveg_types; o.wind_h = opt->wind_h; o.CORRPREC = opt->CORRPREC;
+  o.IMPLICIT = opt->IMPLICIT;
   if (hipSetDevice(device) != hipSuccess) { delete c; return VICGPU_ERR_HIP; }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess
@@ -1477,6 +1511,12 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
     HIPCHK(c, fill_on(c->stream, c->d_hstate, 0, sizeof(int) * nhru));
     HIPCHK(c, fill_on(c->stream, c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, fill_on(c->stream, c->d_pout, 0, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
+    if (c->o.IMPLICIT) {
+      HIPCHK(c, hipMalloc(&c->d_pimp, sizeof(double) * (size_t)Nn * PIMP * nhru));
+      HIPCHK(c, hipMalloc(&c->d_lastexp, sizeof(int) * nhru));
+      HIPCHK(c, fill_on(c->stream, c->d_pimp, 0, sizeof(double) * (size_t)Nn * PIMP * nhru));
+      HIPCHK(c, fill_on(c->stream, c->d_lastexp, 0xFF, sizeof(int) * nhru));
+    }
     // frozen-node root finder (vic_profile.hpp): the option, overridable for A/B runs
     c->node_newton = c->opt.NODE_SOLVER == VIC_NODE_SOLVER_NEWTON;
     if (const char* ev = getenv("VICGPU_NODE_SOLVER")) c->node_newton = (strcmp(ev, "newton") == 0);
@@ -1503,6 +1543,10 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
       HIPCHK(c, hipMalloc(&ch.d_list[0], gb * NBUCKET));
       HIPCHK(c, hipMalloc(&ch.d_list[1], gb * NBUCKET));
       HIPCHK(c, hipMalloc(&ch.d_count, sizeof(int) * CNT_TOTAL));
+      if (c->o.IMPLICIT) {
+        HIPCHK(c, hipMalloc(&ch.d_fb_list, gb * NBUCKET));
+        HIPCHK(c, hipMalloc(&ch.d_fb_count, sizeof(int) * NBUCKET));
+      }
       HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * CNT_TOTAL * 2, hipHostMallocDefault));
       if (ch.gcount) HIPCHK(c, copy_on(c->stream, ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
       HIPCHK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
@@ -1733,7 +1777,7 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   ka.veglib = c->d_veglib; ka.cell_params = c->d_cp; ka.hpi = c->d_hpi; ka.hpd = c->d_hpd;
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
   ka.glist = nullptr; ka.gcount = c->nhru;
-  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.pslot = c->d_pslot; ka.hstate = c->d_hstate; ka.hkey = c->d_hkey; ka.list = nullptr; ka.count = nullptr; ka.list_cap = 0;
+  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.pslot = c->d_pslot; ka.hstate = c->d_hstate; ka.hkey = c->d_hkey; ka.pimp = c->d_pimp; ka.lastexp = c->d_lastexp; ka.list = nullptr; ka.count = nullptr; ka.list_cap = 0;
   ka.phase = 0;
   CArgs& ca = plan.ca;
   ca.ncell = c->ncell; ca.nhru = c->nhru; ca.c0 = 0; ca.ccount = c->ncell;
