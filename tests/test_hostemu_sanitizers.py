@@ -26,10 +26,10 @@ def hostemu_lib(oracle_lib):
     return os.path.join(ROOT, "tools", "hostemu", "libvicgpu_hostemu.so"), rt
 
 
-def _run(lib, rt, args, poison, **extra_env):
+def _run(lib, rt, args, poison, script="check.py", **extra_env):
     env = dict(os.environ, **extra_env, LD_PRELOAD=rt, VICGPU_LIB=lib, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", HOSTEMU_POISON="1" if poison else "0")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hostemu", "check.py")] + args, env=env, cwd=ROOT,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hostemu", script)] + args, env=env, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     report = [l for l in p.stderr.splitlines() if "runtime error" in l or "ERROR: AddressSanitizer" in l]
     assert not report, "\n".join(report[:10])
@@ -41,7 +41,7 @@ def _run(lib, rt, args, poison, **extra_env):
 def test_monolithic_kernel_clean(hostemu_lib, poison):
     """vic_hru_step (QUICK_FLUX, water balance, glacier HRUs, gauge correction) + vic_cell_reduce."""
     out = _run(*hostemu_lib, ["6", "4", "quickflux_melt", "bands", "waterbalance_daily", "glacier_summer", "corrprec_glacier"], poison)
-    assert out.count("worst rel diff") == 5
+    assert out.count("worst rel diff") == 4
 
 
 @pytest.mark.parametrize("poison", [False, True])
@@ -56,3 +56,11 @@ def test_fd_pipeline_newton_and_generic_kernel_clean(hostemu_lib):
     (8 nodes), and the sub-stepped water-balance case."""
     out = _run(*hostemu_lib, ["3", "2", "frozen_fixed", "frozen_wb_daily", "frozen_fixed_n8"], False, VICGPU_NODE_SOLVER="newton")
     assert out.count("worst rel diff") == 3
+
+
+@pytest.mark.parametrize("poison", [False, True])
+def test_round2_entry_points_clean(hostemu_lib, poison):
+    """put_data (three kernels), state-file records (gather and scatter), forcing prefetch / swap with the on-device
+    derivation of atmos[rec], and the IMPLICIT profile kernel with its explicit fall-back."""
+    out = _run(*hostemu_lib, ["3"], poison, script="check_round2.py")
+    assert out.count("worst rel diff") == 4
