@@ -188,6 +188,34 @@ class RefModel(_Model):
             out[name.value.decode()] = (v, ne.value, ag.value)
         return out
 
+    def binding_tables(self):
+        """What integration/vicgpu_binding.cpp packs from the harness's reference structs: dict of its tables (its own HRU
+        numbering) + the vicgpu_options it derives from ProgramState."""
+        from vic_amd import abi
+        d, o = self.dom, self.dom.opt
+        t = dict(veglib=np.zeros((o.nveg_types + 4, C["VL_NFIELD"])), cell_params=np.zeros((abi.cp_nrow(o.Nnode, o.Nband), d.ncell)),
+                 hpi=np.zeros((C["HPI_NROW"], d.nhru), dtype=np.int32), hpd=np.zeros((C["HPD_NROW"], d.nhru)),
+                 cell_off=np.zeros(d.ncell + 1, dtype=np.int32), cell_list=np.zeros(d.nhru, dtype=np.int32),
+                 sd=np.zeros((abi.sd_nrow(o.Nnode), d.nhru)), si=np.zeros((abi.si_nrow(o.Nnode), d.nhru), dtype=np.int32), opt=abi.Options())
+        f = self.lib.vicref_binding_tables; f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, _dp, _dp, _ip, _dp, _ip, _ip, _dp, _ip, ctypes.POINTER(abi.Options)]
+        assert f(self.h, _d(t["veglib"]), _d(t["cell_params"]), _i(t["hpi"]), _d(t["hpd"]), _i(t["cell_off"]), _i(t["cell_list"]),
+                 _d(t["sd"]), _i(t["si"]), ctypes.byref(t["opt"])) == 0
+        return t
+
+    def run_through_binding(self, forcing, snowflag, dmy, device=0):
+        """All steps through VicGpuBinding (the reference-side binding) on the GPU; libvicgpu.so is loaded globally first so
+        that the binding's vicgpu_* calls resolve.  Returns the per-cell error flags."""
+        from vic_amd import api
+        ctypes.CDLL(os.environ.get("VICGPU_LIB", api.LIB_PATH), mode=os.RTLD_GLOBAL | os.RTLD_NOW)
+        forcing = np.ascontiguousarray(forcing); snowflag = np.ascontiguousarray(snowflag); dmy = np.ascontiguousarray(dmy, dtype=np.int32)
+        flags = np.zeros(self.dom.ncell, dtype=np.int32)
+        f = self.lib.vicref_run_through_binding; f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte), _ip, ctypes.c_int, _ip]
+        rc = f(self.h, forcing.shape[0], _d(forcing), snowflag.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _i(dmy), int(device), _i(flags))
+        assert rc == 0, "binding returned %d" % rc
+        return flags
+
     def state_stream(self):
         """The reference's own state-file stream of every cell (processCellForStateFile into a memory back-end):
         (values, variable ids, cell_start[ncell + 1])."""

@@ -25,7 +25,7 @@ OUT="$REPO/oracle/_ref"
 if [ ! -d "$REF" ]; then echo "build_ref: $REF not present, skipping"; exit 0; fi
 mkdir -p "$OUT"
 STAMP="$OUT/.stamp"
-SRC_SUM=$( (cat "$HERE/vicref_shim.cpp" "$HERE/build_ref.sh" "$REPO/include/vicgpu.h"; ls -l "$REF"/*.c "$REF"/*.h) | md5sum | cut -d' ' -f1)
+SRC_SUM=$( (cat "$HERE/vicref_shim.cpp" "$HERE/build_ref.sh" "$REPO/include/vicgpu.h" "$REPO/include/vicgpu_out.h" "$REPO"/integration/vicgpu_binding.*; ls -l "$REF"/*.c "$REF"/*.h) | md5sum | cut -d' ' -f1)
 if [ -f "$STAMP" ] && [ "$(cat "$STAMP")" = "$SRC_SUM" ] && [ -f "$OUT/libvicref.so" ] && [ -f "$OUT/libvicref_compat.so" ] && [ -f "$OUT/libvicref_fixed.so" ]; then
   echo "build_ref: up to date"; exit 0
 fi
@@ -37,7 +37,7 @@ rm -f user_def.h
 sed 's/^#define NETCDF_OUTPUT_AVAILABLE TRUE/#define NETCDF_OUTPUT_AVAILABLE FALSE/' "$REF/user_def.h" > user_def.h
 grep -q '^#define NETCDF_OUTPUT_AVAILABLE FALSE' user_def.h
 SKIP=" vicNl.c close_files.c make_in_and_outfiles.c read_atmos_data.c WriteOutputContext.c StateIONetCDF.c WriteOutputNetCDF.c frozen_soil.c "
-CXXFLAGS="-I. -I$REPO/include -O2 -std=c++11 -fopenmp -fPIC -w -include iostream -DSOURCE_VERSION=\"ref\" -DCOMPILE_TIME=\"x\" -DMACHINE_INFO=\"x\""
+CXXFLAGS="-I. -I$REPO/include -I$REPO/integration -O2 -std=c++11 -fopenmp -fPIC -w -include iostream -DSOURCE_VERSION=\"ref\" -DCOMPILE_TIME=\"x\" -DMACHINE_INFO=\"x\""
 mkdir obj
 compile() { g++ $CXXFLAGS -c "$1" -o "$2"; }
 export -f compile; export CXXFLAGS
@@ -59,6 +59,9 @@ sed -i -e 's/NOFLUX, EXP_TRANS, T0, moist, ice, kappa, Cs, soil_con->max_moist,/
 g++ $CXXFLAGS -c fs_compat.cpp -o fs_compat.o
 g++ $CXXFLAGS -c fs_fixed.cpp -o fs_fixed.o
 g++ $CXXFLAGS -c "$HERE/vicref_shim.cpp" -o shim.o
+# the reference-side binding (integration/): compiled against the reference headers, linked into the harness; its vicgpu_*
+# calls stay unresolved here and bind when libvicgpu.so is in the process (tests/test_binding.py)
+g++ $CXXFLAGS -c "$REPO/integration/vicgpu_binding.cpp" -o binding.o
 ar rcs libvic.a obj/*.o
 for v in plain compat fixed; do
   name=libvicref.so; [ $v = plain ] || name=libvicref_$v.so
@@ -66,7 +69,7 @@ for v in plain compat fixed; do
   # of the left-out I/O files (WriteOutputContext ctor, read_atmos_data) stay unresolved: they are only
   # reachable from state-file / settings-dump code that the harness never calls, so they are left as
   # lazily-bound PLT entries (load the library with RTLD_LAZY) instead of being stubbed.
-  g++ -shared -fopenmp -o "$OUT/$name" shim.o fs_$v.o -Wl,--start-group libvic.a -Wl,--end-group \
+  g++ -shared -fopenmp -o "$OUT/$name" shim.o binding.o fs_$v.o -Wl,--start-group libvic.a -Wl,--end-group \
       -Wl,--unresolved-symbols=ignore-all -Wl,-z,lazy
 done
 echo "$SRC_SUM" > "$STAMP"

@@ -27,6 +27,7 @@
 
 #include "vicgpu.h"
 #include "vicgpu_out.h"
+#include "vicgpu_binding.h"      /* integration/: the reference-side binding, compiled and exercised here */
 #include "GlacierMassBalanceResult.h"
 
 struct vicref_handle {
@@ -339,99 +340,13 @@ int vicref_get_cell_params(void *hv, double *out) {
 
 int vicref_get_state(void *hv, double *sd, int *si) {
   vicref_handle *h = (vicref_handle *)hv;
-  const int Nn = h->opt.Nnode; const size_t nh = h->nhru;
-  for (int g = 0; g < h->nhru; g++) {
-    const HRU &u = h->cells[h->hru_cell[g]].prcp.hruList[h->hru_pos[g]];
-    const hru_data_struct &cw = u.cell[WET];
-    for (int l = 0; l < 3; l++) {
-      SDP(SD_MOIST0 + l) = cw.layer[l].moist; SDP(SD_ICE0 + l) = cw.layer[l].soil_ice; SDP(SD_LAYER_T0 + l) = cw.layer[l].T;
-    }
-    const energy_bal_struct &e = u.energy;
-    SDP(SD_SNOW_FLUX) = e.snow_flux; SDP(SD_GRND_FLUX) = e.grnd_flux; SDP(SD_DELTAH) = e.deltaH; SDP(SD_FUSION) = e.fusion;
-    SDP(SD_LONGUNDEROUT) = e.LongUnderOut; SDP(SD_TFOLIAGE) = e.Tfoliage;
-    const snow_data_struct &s = u.snow;
-    SDP(SD_SNOW_ALBEDO) = s.albedo; SDP(SD_SNOW_COLDCONTENT) = s.coldcontent; SDP(SD_SNOW_COVERAGE) = s.coverage;
-    SDP(SD_SNOW_DENSITY) = s.density; SDP(SD_SNOW_DEPTH) = s.depth; SDP(SD_SNOW_PACK_TEMP) = s.pack_temp;
-    SDP(SD_SNOW_PACK_WATER) = s.pack_water; SDP(SD_SNOW_CANOPY) = s.snow_canopy; SDP(SD_SNOW_SURF_TEMP) = s.surf_temp;
-    SDP(SD_SNOW_SURF_WATER) = s.surf_water; SDP(SD_SNOW_SWQ) = s.swq; SDP(SD_SNOW_TMP_INT_STORAGE) = s.tmp_int_storage;
-    SDP(SD_SNOW_STORE_SWQ) = s.store_swq; SDP(SD_SNOW_STORE_COVERAGE) = s.store_coverage; SDP(SD_SNOW_SWQ_SLOPE) = s.swq_slope;
-    SDP(SD_SNOW_MAX_SWQ) = s.max_swq;
-    SDP(SD_WDEW) = u.veg_var[WET].Wdew;
-    SDP(SD_GLAC_SURF_TEMP) = u.glacier.surf_temp; SDP(SD_GLAC_WATER_STORAGE) = u.glacier.water_storage;
-    SDP(SD_GLAC_CUM_MASS_BALANCE) = u.glacier.cum_mass_balance;
-    SDP(SD_TCANOPY) = e.Tcanopy; SDP(SD_TSURF) = e.Tsurf; SDP(SD_ALBEDO_OVER) = e.AlbedoOver; SDP(SD_ALBEDO_UNDER) = e.AlbedoUnder;
-    SDP(SD_CANOPY_ADVECTION) = e.canopy_advection; SDP(SD_CANOPY_LATENT) = e.canopy_latent;
-    SDP(SD_CANOPY_LATENT_SUB) = e.canopy_latent_sub; SDP(SD_CANOPY_SENSIBLE) = e.canopy_sensible;
-    SDP(SD_CANOPY_REFREEZE) = e.canopy_refreeze; SDP(SD_ADVECTED_SENSIBLE) = e.advected_sensible;
-    SDP(SD_ADVECTION) = e.advection; SDP(SD_DELTACC) = e.deltaCC; SDP(SD_REFREEZE_ENERGY) = e.refreeze_energy;
-    SDP(SD_MELT_ENERGY) = e.melt_energy; SDP(SD_ERROR) = e.error;
-    SDP(SD_LATENT) = e.latent; SDP(SD_LATENT_SUB) = e.latent_sub; SDP(SD_SENSIBLE) = e.sensible;
-    SDP(SD_LONGOVERIN) = e.LongOverIn; SDP(SD_NETLONGOVER) = e.NetLongOver; SDP(SD_NETSHORTOVER) = e.NetShortOver;
-    SDP(SD_SHORTOVERIN) = e.ShortOverIn; SDP(SD_NETLONGUNDER) = e.NetLongUnder;
-    for (int n = 0; n < Nn; n++) {
-      SDP(VICGPU_SD_NODE(SDN_T, n, Nn)) = e.T[n]; SDP(VICGPU_SD_NODE(SDN_MOIST, n, Nn)) = e.moist[n];
-      SDP(VICGPU_SD_NODE(SDN_ICE, n, Nn)) = e.ice_content[n]; SDP(VICGPU_SD_NODE(SDN_KAPPA, n, Nn)) = e.kappa_node[n];
-      SDP(VICGPU_SD_NODE(SDN_CS, n, Nn)) = e.Cs_node[n];
-      SIP(VICGPU_SI_NODE(SIN_T_FBFLAG, n, Nn)) = e.T_fbflag[n]; SIP(VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn)) = e.T_fbcount[n];
-    }
-    SIP(SI_SNOW_LAST_SNOW) = s.last_snow; SIP(SI_SNOW_MELTING) = s.MELTING ? 1 : 0; SIP(SI_SNOW_SNOW) = s.snow;
-    SIP(SI_SNOW_STORE_SNOW) = s.store_snow; SIP(SI_SNOW_SURF_TEMP_FBCOUNT) = s.surf_temp_fbcount;
-    SIP(SI_SNOW_SURF_TEMP_FBFLAG) = s.surf_temp_fbflag ? 1 : 0;
-    SIP(SI_TSURF_FBCOUNT) = e.Tsurf_fbcount; SIP(SI_TSURF_FBFLAG) = e.Tsurf_fbflag;
-    SIP(SI_TFOLIAGE_FBCOUNT) = e.Tfoliage_fbcount; SIP(SI_TFOLIAGE_FBFLAG) = e.Tfoliage_fbflag;
-    SIP(SI_TCANOPY_FBCOUNT) = e.Tcanopy_fbcount; SIP(SI_TCANOPY_FBFLAG) = e.Tcanopy_fbflag;
-    SIP(SI_GLAC_SURF_TEMP_FBCOUNT) = u.glacier.surf_temp_fbcount; SIP(SI_GLAC_SURF_TEMP_FBFLAG) = u.glacier.surf_temp_fbflag ? 1 : 0;
-    SIP(SI_FROZEN) = e.frozen; SIP(SI_NFROST) = e.Nfrost; SIP(SI_NTHAW) = e.Nthaw;
-  }
+  vicgpu_binding_state_to_tables(h->cells, h->hru_cell.data(), h->hru_pos.data(), h->nhru, h->opt.Nnode, sd, si);   /* integration/vicgpu_binding.cpp */
   return 0;
 }
 
 int vicref_set_state(void *hv, const double *sd, const int *si) {
   vicref_handle *h = (vicref_handle *)hv;
-  const int Nn = h->opt.Nnode; const size_t nh = h->nhru;
-  for (int g = 0; g < h->nhru; g++) {
-    HRU &u = h->cells[h->hru_cell[g]].prcp.hruList[h->hru_pos[g]];
-    hru_data_struct &cw = u.cell[WET];
-    for (int l = 0; l < 3; l++) {
-      cw.layer[l].moist = SDP(SD_MOIST0 + l); cw.layer[l].soil_ice = SDP(SD_ICE0 + l); cw.layer[l].T = SDP(SD_LAYER_T0 + l);
-    }
-    energy_bal_struct &e = u.energy;
-    e.snow_flux = SDP(SD_SNOW_FLUX); e.grnd_flux = SDP(SD_GRND_FLUX); e.deltaH = SDP(SD_DELTAH); e.fusion = SDP(SD_FUSION);
-    e.LongUnderOut = SDP(SD_LONGUNDEROUT); e.Tfoliage = SDP(SD_TFOLIAGE);
-    snow_data_struct &s = u.snow;
-    s.albedo = SDP(SD_SNOW_ALBEDO); s.coldcontent = SDP(SD_SNOW_COLDCONTENT); s.coverage = SDP(SD_SNOW_COVERAGE);
-    s.density = SDP(SD_SNOW_DENSITY); s.depth = SDP(SD_SNOW_DEPTH); s.pack_temp = SDP(SD_SNOW_PACK_TEMP);
-    s.pack_water = SDP(SD_SNOW_PACK_WATER); s.snow_canopy = SDP(SD_SNOW_CANOPY); s.surf_temp = SDP(SD_SNOW_SURF_TEMP);
-    s.surf_water = SDP(SD_SNOW_SURF_WATER); s.swq = SDP(SD_SNOW_SWQ); s.tmp_int_storage = SDP(SD_SNOW_TMP_INT_STORAGE);
-    s.store_swq = SDP(SD_SNOW_STORE_SWQ); s.store_coverage = SDP(SD_SNOW_STORE_COVERAGE); s.swq_slope = SDP(SD_SNOW_SWQ_SLOPE);
-    s.max_swq = SDP(SD_SNOW_MAX_SWQ);
-    u.veg_var[WET].Wdew = SDP(SD_WDEW);
-    u.glacier.surf_temp = SDP(SD_GLAC_SURF_TEMP); u.glacier.water_storage = SDP(SD_GLAC_WATER_STORAGE);
-    u.glacier.cum_mass_balance = SDP(SD_GLAC_CUM_MASS_BALANCE);
-    e.Tcanopy = SDP(SD_TCANOPY); e.Tsurf = SDP(SD_TSURF); e.AlbedoOver = SDP(SD_ALBEDO_OVER); e.AlbedoUnder = SDP(SD_ALBEDO_UNDER);
-    e.canopy_advection = SDP(SD_CANOPY_ADVECTION); e.canopy_latent = SDP(SD_CANOPY_LATENT);
-    e.canopy_latent_sub = SDP(SD_CANOPY_LATENT_SUB); e.canopy_sensible = SDP(SD_CANOPY_SENSIBLE);
-    e.canopy_refreeze = SDP(SD_CANOPY_REFREEZE); e.advected_sensible = SDP(SD_ADVECTED_SENSIBLE);
-    e.advection = SDP(SD_ADVECTION); e.deltaCC = SDP(SD_DELTACC); e.refreeze_energy = SDP(SD_REFREEZE_ENERGY);
-    e.melt_energy = SDP(SD_MELT_ENERGY); e.error = SDP(SD_ERROR);
-    e.latent = SDP(SD_LATENT); e.latent_sub = SDP(SD_LATENT_SUB); e.sensible = SDP(SD_SENSIBLE);
-    e.LongOverIn = SDP(SD_LONGOVERIN); e.NetLongOver = SDP(SD_NETLONGOVER); e.NetShortOver = SDP(SD_NETSHORTOVER);
-    e.ShortOverIn = SDP(SD_SHORTOVERIN); e.NetLongUnder = SDP(SD_NETLONGUNDER);
-    for (int n = 0; n < Nn; n++) {
-      e.T[n] = SDP(VICGPU_SD_NODE(SDN_T, n, Nn)); e.moist[n] = SDP(VICGPU_SD_NODE(SDN_MOIST, n, Nn));
-      e.ice_content[n] = SDP(VICGPU_SD_NODE(SDN_ICE, n, Nn)); e.kappa_node[n] = SDP(VICGPU_SD_NODE(SDN_KAPPA, n, Nn));
-      e.Cs_node[n] = SDP(VICGPU_SD_NODE(SDN_CS, n, Nn));
-      e.T_fbflag[n] = (char)SIP(VICGPU_SI_NODE(SIN_T_FBFLAG, n, Nn)); e.T_fbcount[n] = SIP(VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn));
-    }
-    s.last_snow = SIP(SI_SNOW_LAST_SNOW); s.MELTING = SIP(SI_SNOW_MELTING) != 0; s.snow = SIP(SI_SNOW_SNOW);
-    s.store_snow = SIP(SI_SNOW_STORE_SNOW); s.surf_temp_fbcount = SIP(SI_SNOW_SURF_TEMP_FBCOUNT);
-    s.surf_temp_fbflag = SIP(SI_SNOW_SURF_TEMP_FBFLAG) != 0;
-    e.Tsurf_fbcount = SIP(SI_TSURF_FBCOUNT); e.Tsurf_fbflag = (char)SIP(SI_TSURF_FBFLAG);
-    e.Tfoliage_fbcount = SIP(SI_TFOLIAGE_FBCOUNT); e.Tfoliage_fbflag = (char)SIP(SI_TFOLIAGE_FBFLAG);
-    e.Tcanopy_fbcount = SIP(SI_TCANOPY_FBCOUNT); e.Tcanopy_fbflag = (char)SIP(SI_TCANOPY_FBFLAG);
-    u.glacier.surf_temp_fbcount = SIP(SI_GLAC_SURF_TEMP_FBCOUNT); u.glacier.surf_temp_fbflag = SIP(SI_GLAC_SURF_TEMP_FBFLAG) != 0;
-    e.frozen = (char)SIP(SI_FROZEN); e.Nfrost = SIP(SI_NFROST); e.Nthaw = SIP(SI_NTHAW);
-  }
+  vicgpu_binding_tables_to_state(h->cells, h->hru_cell.data(), h->hru_pos.data(), h->nhru, h->opt.Nnode, sd, si);
   return 0;
 }
 
@@ -540,6 +455,75 @@ int vicref_state_var_id(const char *name) {
     {"SOIL_ZSUM_NODE", SOIL_ZSUM_NODE}, {"GLAC_MASS_BALANCE_EQN_TERMS", GLAC_MASS_BALANCE_EQN_TERMS}, {"HRU_VEG_VAR_WDEW", HRU_VEG_VAR_WDEW}};
   for (size_t i = 0; i < sizeof(t) / sizeof(t[0]); i++) if (strcmp(name, t[i].n) == 0) return t[i].v;
   return -1;
+}
+
+/* ---- the reference-side binding (integration/vicgpu_binding.cpp) on the harness's cells.
+ * vicref_binding_tables: what the binding packs from the reference structs (its own HRU numbering), for the round-trip test:
+ * the tables the harness was built from must come back.  Buffers sized by the caller from ncell / nhru. */
+int vicref_binding_tables(void *hv, double *veglib, double *cell_params, int *hpi, double *hpd, int *cell_off, int *cell_list,
+                          double *sd, int *si, vicgpu_options *opt_out) {
+  vicref_handle *h = (vicref_handle *)hv;
+  VicGpuTables t;
+  vicgpu_binding_options(&h->state, opt_out);
+  vicgpu_binding_number_hrus(h->cells, t);
+  vicgpu_binding_pack_veglib(&h->state, t);
+  vicgpu_binding_pack_domain(&h->state, h->cells, t);
+  if (t.nhru != h->nhru || t.ncell != h->ncell) return -1;
+  t.sd.assign((size_t)VICGPU_SD_NROW(t.Nnode) * t.nhru, 0.0); t.si.assign((size_t)VICGPU_SI_NROW(t.Nnode) * t.nhru, 0);
+  vicgpu_binding_state_to_tables(h->cells, t.hru_cell.data(), t.hru_pos.data(), t.nhru, t.Nnode, t.sd.data(), t.si.data());
+  memcpy(veglib, t.veglib.data(), sizeof(double) * t.veglib.size());
+  memcpy(cell_params, t.cell_params.data(), sizeof(double) * t.cell_params.size());
+  memcpy(hpi, t.hpi.data(), sizeof(int) * t.hpi.size()); memcpy(hpd, t.hpd.data(), sizeof(double) * t.hpd.size());
+  memcpy(cell_off, t.cell_off.data(), sizeof(int) * t.cell_off.size()); memcpy(cell_list, t.cell_list.data(), sizeof(int) * t.cell_list.size());
+  memcpy(sd, t.sd.data(), sizeof(double) * t.sd.size()); memcpy(si, t.si.data(), sizeof(int) * t.si.size());
+  return 0;
+}
+
+/* nsteps records through VicGpuBinding (libvicgpu.so must be loaded in the process: the vicgpu_* symbols bind lazily): the
+ * cells get an atmos[] array of nsteps records like the one initialize_atmos builds, the binding replaces the cell loop of
+ * vicNl.c:506-593, and the device state ends up back in the cells' HRU structs.  frozen_compat / node_solver: the two
+ * vicgpu_options fields that are not reference options.  Returns 0, or 100 + the binding's error, flags[ncell] = ERROR flags. */
+int vicref_run_through_binding(void *hv, int nsteps, const double *forcing, const unsigned char *snowflag, const int *dmyv, int device,
+                               int *flags) {
+  vicref_handle *h = (vicref_handle *)hv;
+  const size_t ns = h->NR + 1, nc = h->ncell;
+  std::vector<atmos_data_struct *> saved(h->ncell);
+  for (int c = 0; c < h->ncell; c++) {
+    saved[c] = h->cells[c].atmos;
+    atmos_data_struct *arr = (atmos_data_struct *)calloc(nsteps, sizeof(atmos_data_struct));
+    for (int r = 0; r < nsteps; r++) { atmos_data_struct *one = make_atmos(h->NR); arr[r] = *one; free(one); }
+    h->cells[c].atmos = arr;
+  }
+  std::vector<dmy_struct> dmy(nsteps);
+  for (int r = 0; r < nsteps; r++) {
+    memset(&dmy[r], 0, sizeof(dmy_struct));
+    dmy[r].month = dmyv[r * VIC_NDMY + VIC_DMY_MONTH]; dmy[r].day_in_year = dmyv[r * VIC_NDMY + VIC_DMY_DAY_IN_YEAR];
+    dmy[r].hour = dmyv[r * VIC_NDMY + VIC_DMY_HOUR]; dmy[r].day = dmyv[r * VIC_NDMY + VIC_DMY_DAY]; dmy[r].year = dmyv[r * VIC_NDMY + VIC_DMY_YEAR];
+    for (int c = 0; c < h->ncell; c++) {
+      atmos_data_struct *keep = h->cells[c].atmos;
+      h->cells[c].atmos = &keep[r];
+      load_atmos(h, c, forcing + (size_t)r * VIC_NFORCE * ns * nc, snowflag + (size_t)r * ns * nc);
+      h->cells[c].atmos = keep;
+    }
+  }
+  int rc = 0;
+  {
+    /* the two fields of vicgpu_options that are not options of the reference come from the harness's own options */
+    VicGpuBinding b(&h->state, h->cells, device, h->opt.frozen_compat, h->opt.NODE_SOLVER);
+    if (!b.ok()) rc = 100;
+    if (!rc) { int r = b.run(0, nsteps, dmy.data()); if (r) rc = 100 - r; }
+    if (!rc) { int r = b.finish(flags); if (r) rc = 100 - r; }
+  }
+  for (int c = 0; c < h->ncell; c++) {
+    atmos_data_struct *arr = h->cells[c].atmos;
+    for (int r = 0; r < nsteps; r++) {
+      free(arr[r].air_temp); free(arr[r].channel_in); free(arr[r].density); free(arr[r].longwave); free(arr[r].prec); free(arr[r].pressure);
+      free(arr[r].shortwave); free(arr[r].snowflag); free(arr[r].tskc); free(arr[r].vp); free(arr[r].vpd); free(arr[r].wind);
+    }
+    free(arr);
+    h->cells[c].atmos = saved[c];
+  }
+  return rc;
 }
 
 /* ---- the reference's own put_data (put_data.c:7) on the harness's cells, for pinning oracle/orc_putdata.c.
