@@ -1,7 +1,8 @@
 #!/bin/bash
-for so in vic_amd/libvicgpu.so tools/exp/variants/*.so; do
+# same-box A/B of library variants on the bench workloads (ms per step; default cfg3)
+for so in tools/exp/variants/*.so; do
   n=$(basename $so .so)
-  for cfg in cfg3 cfg2; do
+  for cfg in ${CFGS:-cfg3}; do
     VICGPU_LIB=$PWD/$so timeout -k 10 300 python bench.py --config $cfg --steps 12 --warmup 4 --no-cpu-baseline --no-strict-leg --no-stream-leg > gpurun_out/vbench_${n}_$cfg.json 2> gpurun_out/vbench_${n}_$cfg.err
     python - <<PY
 import json

@@ -90,10 +90,22 @@ struct KArgs {
 // Plain structs are parked word by word.  The table is tiled by wave: [hru / 64][word][hru % 64], so one wave's whole
 // context is a single contiguous slab (coalesced 512-byte rows, a handful of pages) instead of one row per word
 // spread over the whole table.
+#ifndef VIC_CTX_AOS
+#define VIC_CTX_AOS 0
+#endif
+#if VIC_CTX_AOS
+constexpr size_t CTX_WORD_STRIDE = 1;     // [hru][word]: one HRU's context is one contiguous block
+#else
+constexpr size_t CTX_WORD_STRIDE = 64;    // [hru / 64][word][hru % 64]
+#endif
 struct CtxRef {
-  unsigned long long* p;    // slab of this lane's wave, offset by the lane
+  unsigned long long* p;    // word 0 of this HRU
   VIC_DEV static CtxRef at(unsigned long long* base, size_t words_per_hru, size_t g) {
+#if VIC_CTX_AOS
+    return CtxRef{base + g * words_per_hru};
+#else
     return CtxRef{base + (g >> 6) * (words_per_hru * 64) + (g & 63)};
+#endif
   }
 };
 template <class T>
@@ -102,18 +114,18 @@ VIC_DEV void ctx_put(const CtxRef& r, size_t word0, const T& v) {
   constexpr int NW = sizeof(T) / 8;
   unsigned long long tmp[NW];
   __builtin_memcpy(tmp, &v, sizeof(T));
-  unsigned long long* __restrict__ q = r.p + word0 * 64;
+  unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
-  for (int i = 0; i < NW; i++) q[(size_t)i * 64] = tmp[i];
+  for (int i = 0; i < NW; i++) q[(size_t)i * CTX_WORD_STRIDE] = tmp[i];
 }
 template <class T>
 VIC_DEV void ctx_get(const CtxRef& r, size_t word0, T& v) {
   static_assert(sizeof(T) % 8 == 0 && std::is_trivially_copyable<T>::value, "context structs are arrays of 8-byte words");
   constexpr int NW = sizeof(T) / 8;
   unsigned long long tmp[NW];
-  const unsigned long long* __restrict__ q = r.p + word0 * 64;
+  const unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
-  for (int i = 0; i < NW; i++) tmp[i] = q[(size_t)i * 64];
+  for (int i = 0; i < NW; i++) tmp[i] = q[(size_t)i * CTX_WORD_STRIDE];
   __builtin_memcpy(&v, tmp, sizeof(T));
 }
 constexpr size_t CW_SV = sizeof(SurfSolve) / 8, CW_EBM = sizeof(SurfEBMut) / 8, CW_EBC = sizeof(SurfEBConst) / 8,
@@ -131,20 +143,20 @@ VIC_DEV void ctx_put_words(const CtxRef& r, size_t word0, const T& v, int first,
   constexpr int NW = sizeof(T) / 8;
   unsigned long long tmp[NW];
   __builtin_memcpy(tmp, &v, sizeof(T));
-  unsigned long long* __restrict__ q = r.p + word0 * 64;
+  unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
   for (int i = 0; i < NW; i++)
-    if (i >= first && i < last) q[(size_t)i * 64] = tmp[i];
+    if (i >= first && i < last) q[(size_t)i * CTX_WORD_STRIDE] = tmp[i];
 }
 template <class T>
 VIC_DEV void ctx_get_words(const CtxRef& r, size_t word0, T& v, int first, int last) {
   constexpr int NW = sizeof(T) / 8;
   unsigned long long tmp[NW];
   __builtin_memcpy(tmp, &v, sizeof(T));
-  const unsigned long long* __restrict__ q = r.p + word0 * 64;
+  const unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
   for (int i = 0; i < NW; i++)
-    if (i >= first && i < last) tmp[i] = q[(size_t)i * 64];
+    if (i >= first && i < last) tmp[i] = q[(size_t)i * CTX_WORD_STRIDE];
   __builtin_memcpy(&v, tmp, sizeof(T));
 }
 
