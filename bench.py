@@ -105,6 +105,7 @@ def cpu_baseline(cfg, target_seconds=15.0):
     rate = ncell_s * nsteps / secs
     nsteps = 12
     ncell_s = int(min(cfg["ncell"], max(2048, target_seconds * rate / nsteps)))
+    nsteps = int(min(2400, max(12, target_seconds * rate / ncell_s)))      # small domains: more steps instead of more cells
     secs, nthreads = run(ncell_s, nsteps)
     rate = ncell_s * nsteps / secs
     return {"value": rate, "unit": "cell-timesteps/s", "cores": nthreads, "kind": kind,

@@ -3,7 +3,7 @@
 # WRITE_SIZE in separate PMC passes (they do not fit one pass on gfx950).  Output under gpurun_out/round/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/round
+O=$R/gpurun_out/${ROUND_DIR:-round}
 rm -rf $O && mkdir -p $O
 ARGS=${BENCH_ARGS:---steps 6 --warmup 2 --no-cpu-baseline --no-strict-leg --no-stream-leg}
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 $R/bench.py $ARGS > $O/bench_trace.log 2>&1 || exit 1

@@ -18,7 +18,7 @@ suffix = sys.argv[5] if len(sys.argv) > 5 else ""
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-src = os.path.join(ROOT, "gpurun_out", "round")
+src = os.path.join(ROOT, "gpurun_out", os.environ.get("ROUND_DIR", "round"))
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(dst, "%s_%s%s_kernel_stats.csv" % (tag, config, suffix)))
