@@ -1126,7 +1126,10 @@ static void free_domain(vicgpu_ctx* c) {
 template <int NN>
 static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool ordinary, bool glacier) {
   const int nblk = (ka.gcount + 63) / 64;
-  if (ordinary) hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), 0, st, ka);
+  // ordinary HRUs run the monolithic kernel with QUICK_FLUX only (Nnode == 3); the other node counts never instantiate it
+  if constexpr (NN == 3) {
+    if (ordinary) hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), 0, st, ka);
+  }
   if (glacier) hipLaunchKernelGGL((vic_hru_step<NN, true>), dim3(nblk), dim3(64), 0, st, ka);
   return hipGetLastError();
 }
