@@ -7,7 +7,7 @@ import pytest
 
 from vic_amd import abi, domain
 from vic_amd.abi import C
-from tests.util import rel_diff, worst
+from tests.util import edge_domain, rel_diff, worst
 
 FROZEN = dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=0)
 CASES = [
@@ -17,6 +17,8 @@ CASES = [
     ("glacier_agg6", dict(FULL_ENERGY=1, Nband=3), "plain", 6, 2, True, 96, 150, 6),
     ("glacier_frozen", dict(FROZEN, Nband=2), "fixed", 4, 2, True, 72, 110, 3),
     ("stress_fallback", dict(FULL_ENERGY=1, TFALLBACK=1), "plain", 6, 3, False, 48, 70, 4),
+    # artificial bare-soil HRUs, Cv = 0 tiles, a band without area, ragged HRU lists and a cell without any HRU (tests/util.py)
+    ("irregular", dict(FULL_ENERGY=1, Nband=3), "plain", 12, 3, False, 48, 70, 6),
 ]
 AGG = {0: "AGG_TYPE_AVG", 1: "AGG_TYPE_BEG", 2: "AGG_TYPE_END", 3: "AGG_TYPE_MAX", 4: "AGG_TYPE_MIN", 5: "AGG_TYPE_SUM"}   # vicNl_def.h
 
@@ -48,7 +50,7 @@ def test_oracle_put_data_vs_reference(case, oracle_lib, ref_available):
         pytest.skip("reference build (oracle/_ref) not available")
     name, kw, variant, ncell, ntile, glacier, nsteps, doy, ratio = case
     opt = abi.default_options(**kw)
-    d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
+    d = edge_domain(opt, ncell=ncell, ntile=ntile) if name == "irregular" else domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
     f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
     if name == "stress_fallback":
         f[5::7, C["VIC_F_SHORTWAVE"]][..., np.arange(d.ncell) % 3 == 1] = 60000.0
@@ -99,6 +101,8 @@ GPU_CASES = [
     ("frozen_bands_newton", dict(FROZEN, Nband=2), 12, 3, False, 36, 80, 12, "newton"),
     ("glacier_agg6", dict(FULL_ENERGY=1, Nband=3), 70, 2, True, 36, 150, 6, "brent"),
     ("glacier_frozen", dict(FROZEN, Nband=2), 12, 2, True, 36, 110, 3, "brent"),
+    ("irregular", dict(FULL_ENERGY=1, Nband=3), 24, 3, False, 24, 70, 4, "brent"),
+    ("irregular_frozen", dict(FROZEN, Nband=3), 12, 3, False, 12, 80, 3, "brent"),
 ]
 # differences of nearly equal storages and balance residuals: compared absolutely (mm, W/m2)
 DIFF_VARS = ("OUT_DELSOILMOIST", "OUT_DELSWE", "OUT_DELINTERCEPT", "OUT_DELSURFSTOR", "OUT_WATER_ERROR", "OUT_ENERGY_ERROR")
@@ -132,7 +136,7 @@ def test_device_put_data_against_oracle(case, oracle_lib):
     from vic_amd.api import Model
     name, kw, ncell, ntile, glacier, nsteps, doy, ratio, solver = case
     opt = abi.default_options(**dict(kw, NODE_SOLVER=C["VIC_NODE_SOLVER_NEWTON" if solver == "newton" else "VIC_NODE_SOLVER_BRENT"]))
-    d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
+    d = edge_domain(opt, ncell=ncell, ntile=ntile) if name.startswith("irregular") else domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
     f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
     sd0, si0 = init_state.initial_state(d, f[0])
     if glacier:

@@ -1537,6 +1537,12 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
     if (const char* ev = getenv("VICGPU_NODE_SOLVER")) c->node_newton = (strcmp(ev, "newton") == 0);
     c->profile_waves = (Nn == 10) ? profile_resident_waves<10>(c->device, c->node_newton)
                                   : profile_resident_waves<VIC_MAX_NODES>(c->device, c->node_newton);
+    // tuning: a fraction of the resident profile waves (VICGPU_PROFILE_WAVES_PCT), so that the kernels of another cell chunk
+    // (VICGPU_CHUNKS > 1) find free SIMD slots beside them
+    if (const char* ev = getenv("VICGPU_PROFILE_WAVES_PCT")) {
+      const int pct = atoi(ev);
+      if (pct >= 5 && pct <= 100) c->profile_waves = c->profile_waves * pct / 100 > 0 ? c->profile_waves * pct / 100 : 1;
+    }
     // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  One chunk is the
     // default: the persistent profile kernel fills every SIMD, so concurrent chunks mostly queue behind each other.
     int nchunk = 1;
