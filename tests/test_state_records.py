@@ -133,3 +133,12 @@ def test_device_state_records(case, oracle_lib):
     bad = rec_g.copy(); bad[3, C["SR_VEG_CLASS"]] += 1
     with pytest.raises(VicGpuError):
         gpu2.set_state_records(bad)
+    # interrupted == uninterrupted, bit for bit: device A runs 2k steps; device B runs k, hands its records and its tables to
+    # a new context (tables first, the records scattered on top of them), which runs the other k
+    a = Model(d); a.set_state(sd0, si0); a.push_forcing(f, sf, dmy); a.dist_prec(0, 2 * nsteps)
+    b = Model(d); b.set_state(sd0, si0); b.push_forcing(f, sf, dmy); b.dist_prec(0, nsteps)
+    rec_b, (sd_b, si_b), fx_b = b.get_state_records(), b.get_state(), b.get_fluxes()
+    c2 = Model(d); c2.set_state(sd_b, si_b); c2.set_fluxes(fx_b); c2.set_state_records(rec_b)
+    c2.push_forcing(f, sf, dmy); c2.dist_prec(nsteps, nsteps)
+    (sa, ia), (sc, ic) = a.get_state(), c2.get_state()
+    assert np.array_equal(sa, sc, equal_nan=True) and np.array_equal(ia, ic)
