@@ -91,12 +91,16 @@ VIC_DEV void profile_item_store(const Opt& o, const CellView& cv, const Soil3& s
 // Residual of the ground-surface energy balance (func_surf_energy_bal.c:9-403).  Plain data, so that the evaluation
 // kernel can park it in HBM between the rounds of the Brent iteration on Tsurf: Const is written once per sub-step,
 // Mut ("last evaluation wins", the reference passes these by pointer) after every evaluation.
-struct SurfEBConst {
+// The residual's inputs that depend on the cell, the vegetation class and the forcing only: not parked, every kernel that
+// needs a SurfEB fills them from their (cache-resident) tables (surf_cell_fill) -- 16 words less context per evaluation.
+struct SurfEBCell {
   VegMonth vm;
-  int VEG, frozen_on, INCLUDE_SNOW, SNOWING, overstory, pad_;
-  double delta_t, Cs1, Cs2, D1, D2, T1_old, T2, Ts_old, bubble, dp, expt, ice0, kappa1, kappa2, max_moist, moist, elevation,
-         b_infilt, resid0;
-  double NetShortBare, NetShortGrnd, NetShortSnow, Tair, atmos_density, atmos_pressure, LongBareIn, LongSnowIn, surf_atten, vp, vpd;
+  double D1, D2, bubble, dp, expt, max_moist, elevation, b_infilt, resid0, atmos_density, atmos_pressure;
+};
+struct SurfEBConst {
+  int VEG, frozen_on, INCLUDE_SNOW, SNOWING, overstory, hidx;      // hidx: the forcing sub-step of this root find
+  double delta_t, Cs1, Cs2, T1_old, T2, Ts_old, ice0, kappa1, kappa2, moist;
+  double NetShortBare, NetShortGrnd, NetShortSnow, Tair, LongBareIn, LongSnowIn, surf_atten, vp, vpd;
   double Wdew, rainfall, Le, Advection, OldTSurf, kappa_snow, melt_energy, snow_coverage, snow_density, snow_swq, snow_water;
   double U_under, zref_under, disp_under, z0_under, ra_under;
   double lmoist[3], lice[3], root[3];
@@ -113,7 +117,7 @@ struct SurfEBMut {
   double NetLongBare, T1, deltaH, grnd_flux, latent_heat, latent_heat_sub, sensible_heat, snow_flux, error;
 };
 
-struct SurfEB : SurfEBConst, SurfEBMut {
+struct SurfEB : SurfEBCell, SurfEBConst, SurfEBMut {
   // T1_fd / T2_fd: nodes 1 and 2 of the finite-difference profile solved for this Ts (ignored with QUICK_FLUX)
   VIC_DEV double eval(const Opt& o, const Soil3& s3, double Ts, double T1_fd, double T2_fd) {
     PROF_WAVE(7); PROF_LANE(8);
@@ -260,6 +264,17 @@ VIC_DEV void surf_solve_consume(const Opt& o, SurfSolve& sv, SurfEBMut& m, doubl
 
 // calc_surf_energy_bal.c:7-428: everything before the root finder.  lmoist/lice/layerevap are the three soil layers of
 // the current sub-step.
+// the SurfEBCell part, from the tables (the expressions of calc_surf_energy_bal.c:225-262 as surf_setup had them)
+VIC_DEV void surf_cell_fill(SurfEBCell& c, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, int hidx, int veg_idx,
+                            int month) {
+  c.vm = veg_month(vl, veg_idx, month);
+  c.D1 = cv.node(CPN_ZSUM, 1) - cv.node(CPN_ZSUM, 0); c.D2 = cv.node(CPN_ZSUM, 2) - cv.node(CPN_ZSUM, 1);
+  c.bubble = cv.lay(CPL_BUBBLE, 0); c.dp = cv.s(CP_DP); c.expt = cv.lay(CPL_EXPT, 0);
+  c.max_moist = s3.max_moist[0] / (s3.depth[0] * 1000.);
+  c.elevation = cv.s(CP_ELEVATION); c.b_infilt = cv.s(CP_B_INFILT); c.resid0 = s3.resid_moist[0];
+  c.atmos_density = fc.v(VIC_F_DENSITY, hidx); c.atmos_pressure = fc.v(VIC_F_PRESSURE, hidx);
+}
+
 template <int NN>
 VIC_DEV void surf_setup(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, int hidx, int veg_idx,
                         int month, bool is_artificial_bare, bool overstory, double Le, double LongUnderIn, double NetLongSnow,
@@ -272,7 +287,8 @@ VIC_DEV void surf_setup(const Opt& o, const CellView& cv, const VegLib& vl, cons
                         const double* layerevap, const Nodes<NN>& nd, const SoilEnergy& e, const Snow& snow, const VegVar& vv,
                         SurfEB& eb, SurfPost& P, SurfSolve& sv) {
   const int Nn = (NN == VIC_MAX_NODES) ? o.Nnode : NN;
-  const VegMonth vm = veg_month(vl, veg_idx, month);
+  surf_cell_fill(eb, cv, vl, s3, fc, hidx, veg_idx, month);
+  const VegMonth vm = eb.vm;
   const bool frozen_on = (cv.s(CP_FS_ACTIVE) != 0.0) && o.FROZEN_SOIL;
   const double delta_t = (double)dt * 3600.;
   const double kappa_snow = (snow.depth > 0.) ? K_SNOW * (snow.density) * (snow.density) / snow_depth_avg : 0;
@@ -289,18 +305,14 @@ VIC_DEV void surf_setup(const Opt& o, const CellView& cv, const VegLib& vl, cons
   P.rainfall = rainfall; P.NetShortBare = NetShortBare; P.TmpNetShortSnow = TmpNetShortSnow; P.melt_in = melt_in; P.ppt_in = ppt_in;
   P.delta_t = delta_t; P.INCLUDE_SNOW = INCLUDE_SNOW; P.is_artificial_bare = is_artificial_bare;
 
-  eb.vm = vm;
   eb.VEG = (!is_artificial_bare) && (vm.LAI > 0.0);
-  eb.frozen_on = frozen_on; eb.INCLUDE_SNOW = INCLUDE_SNOW != 0; eb.SNOWING = snow.snow != 0; eb.overstory = overstory; eb.pad_ = 0;
+  eb.frozen_on = frozen_on; eb.INCLUDE_SNOW = INCLUDE_SNOW != 0; eb.SNOWING = snow.snow != 0; eb.overstory = overstory; eb.hidx = hidx;
   eb.delta_t = delta_t; eb.Cs1 = e.Cs[0]; eb.Cs2 = e.Cs[1];
-  eb.D1 = cv.node(CPN_ZSUM, 1) - cv.node(CPN_ZSUM, 0); eb.D2 = cv.node(CPN_ZSUM, 2) - cv.node(CPN_ZSUM, 1);
   eb.T1_old = nd.T[1]; eb.T2 = nd.T[Nn - 1 < NN ? Nn - 1 : NN - 1]; eb.Ts_old = nd.T[0];
-  eb.bubble = cv.lay(CPL_BUBBLE, 0); eb.dp = cv.s(CP_DP); eb.expt = cv.lay(CPL_EXPT, 0); eb.ice0 = ice0;
+  eb.ice0 = ice0;
   eb.kappa1 = e.kappa[0]; eb.kappa2 = e.kappa[1];
-  eb.max_moist = s3.max_moist[0] / (s3.depth[0] * 1000.); eb.moist = moist0;
-  eb.elevation = cv.s(CP_ELEVATION); eb.b_infilt = cv.s(CP_B_INFILT); eb.resid0 = s3.resid_moist[0];
+  eb.moist = moist0;
   eb.NetShortBare = NetShortBare; eb.NetShortGrnd = NetShortGrnd; eb.NetShortSnow = TmpNetShortSnow; eb.Tair = Tair;
-  eb.atmos_density = fc.v(VIC_F_DENSITY, hidx); eb.atmos_pressure = fc.v(VIC_F_PRESSURE, hidx);
   eb.LongBareIn = LongBareIn; eb.LongSnowIn = LongSnowIn; eb.surf_atten = surf_atten; eb.vp = VPcanopy; eb.vpd = VPDcanopy;
   eb.Wdew = vv.Wdew; eb.rainfall = rainfall; eb.Le = Le; eb.Advection = e.advection; eb.OldTSurf = OldTSurf;
   eb.kappa_snow = kappa_snow; eb.melt_energy = melt_energy; eb.snow_coverage = snow_coverage; eb.snow_density = snow.density;

@@ -615,6 +615,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
     ctx_get(cx, CO_SV, sv);
     ctx_get(cx, CO_EBM, static_cast<SurfEBMut&>(eb));
     ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
+    surf_cell_fill(eb, cv, vl, s3, fc, eb.hidx, id.veg_idx, a.dmy.month);
     ctx_get(cx, CO_P, P);
     ctx_get_words(cx, CO_L, L, 0, (int)CW_L_HEAD);
     if (MULTI && L.N_steps > 0) ctx_get_words(cx, CO_L, L, (int)CW_L_HEAD, (int)CW_L);
@@ -736,6 +737,9 @@ struct EArgs {
   int* profile_next;     // work-list cursor of the profile kernel, cleared for its next launch
   int* evalonly;         // HRUs that wait for an evaluation without a solve (final evaluation on record)
   int implicit;          // IMPLICIT: the final evaluation is always solved again (its fallback flags depend on the solves before it)
+  const double* veglib;  // for the table-derived part of the residual's inputs (surf_cell_fill)
+  const double* forcing; // this step
+  int month;
 };
 
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const EArgs a) {
@@ -754,6 +758,11 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   ctx_get(cx, CO_SV, sv);
   ctx_get_words(cx, CO_EBM, static_cast<SurfEBMut&>(eb), 0, (int)CW_EBM_FEED);
   ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
+  {
+    const VegLib vl{a.veglib};
+    const Forcing fc{a.forcing, nullptr, a.ncell, c, a.o.NR + 1};
+    surf_cell_fill(eb, cv, vl, s3, fc, eb.hidx, a.hpi[(size_t)HPI_VEG_INDEX * nh + g], a.month);
+  }
   const double* __restrict__ rec = a.pout + (size_t)g * pout_hru_stride(a.Nn);
   // the record the profile kernel has just written, or the one found on record for the final evaluation
   const int slot = sv.on_record ? sv.final_slot : a.pslot[g];
@@ -1219,6 +1228,7 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   ea.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
   ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + CNT_CURSOR; ea.evalonly = ch->d_count + CNT_EVALONLY;
   ea.list_cap = ch->list_cap; ea.hkey = c->d_hkey; ea.implicit = c->o.IMPLICIT;
+  ea.veglib = c->d_veglib; ea.forcing = ka.forcing; ea.month = ka.dmy.month;
   const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
