@@ -363,9 +363,12 @@ def test_chunking_is_invisible(monkeypatch):
         m = Model(d)
         m.set_state(sd0, si0)
         m.push_forcing(f, sf, dmy)
+        m.put_data_config(4); m.put_data_init()            # put_data runs per chunk, on the chunk's stream
         m.dist_prec(0, nsteps)
         sd, si = m.get_state()
-        out.append((sd, si, m.get_fluxes(), m.get_accum(), m.get_cell_errors()))
+        names = [t[0] for t in m.output_list()]
+        out.append((sd, si, m.get_fluxes(), m.get_accum(), m.get_cell_errors(), m.get_output_data(names), m.get_output_data(names, aggregated=True),
+                    m.get_balance()))
         del m
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b, equal_nan=True)
