@@ -6,7 +6,7 @@
 // (state, fluxes, forcing, outputs) is a coalesced 512-byte row segment:
 //   vic_put_sum<PART>   one lane = one cell x one third of the variables (water-balance terms / energy-balance terms / band
 //                       variables).  The cell's HRUs are visited in hruList order (the order put_data.c:260 iterates in), so
-//                       every area-weighted sum is formed in the reference's order of additions.  Scalar sums live in
+//                       every area-weighted sum is formed in the reference's order of additions.  (vic_put_zero clears the rows first.)  Scalar sums live in
 //                       registers and are written once; the band variables, whose row depends on the HRU's band, are
 //                       read-modify-written in one batch per HRU (all loads, then all stores: the rows' offsets are run-time
 //                       values, so the compiler may not reorder a load above an earlier store itself).
@@ -500,6 +500,19 @@ __global__ __launch_bounds__(64) void vic_put_finish(const OArgs a) {
   AG(AERO_RESIST1) = 1 / (g1 + ac1 / a.out_step_ratio);
   AG(AERO_RESIST2) = 1 / (g2 + ac2 / a.out_step_ratio);
 #undef AG
+}
+
+// zero_output_list for the cells of the launch: lane = cell, blockIdx.y = a chunk of 32 rows
+__global__ __launch_bounds__(64) void vic_put_zero(const OArgs a) {
+  const int ci = blockIdx.x * 64 + threadIdx.x;
+  if (ci >= a.ccount) return;
+  const size_t nc = a.ncell;
+  const int nrow = a.lay.off[VOUT_NVAR];
+  double* __restrict__ od = a.out_data + a.c0 + ci;
+  const int r0 = blockIdx.y * PUT_AGG_ROWS;
+#pragma unroll
+  for (int i = 0; i < PUT_AGG_ROWS; i++)
+    if (r0 + i < nrow) od[(size_t)(r0 + i) * nc] = 0.0;
 }
 
 // temporal aggregation, put_data.c:663-682; rowagg[r] = aggregation type of row r's variable

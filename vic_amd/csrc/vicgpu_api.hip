@@ -1299,8 +1299,7 @@ static hipError_t launch_put_data(const vicgpu_ctx* c, hipStream_t st, int c0, i
   a.cell_out = c->d_cell_out; a.out_data = c->d_out_data; a.out_agg = c->d_out_agg; a.pb = c->d_pb;
   const unsigned nblk = (unsigned)((ccount + 63) / 64);
   // zero_output_list: the columns of these cells in every row
-  hipError_t e = hipMemset2DAsync(c->d_out_data + c0, sizeof(double) * c->ncell, 0, sizeof(double) * ccount, c->out_nrow, st);
-  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(vic_put_zero, dim3(nblk, (c->out_nrow + PUT_AGG_ROWS - 1) / PUT_AGG_ROWS), dim3(64), 0, st, a);
   hipLaunchKernelGGL(vic_put_sum, dim3(nblk, PUT_NPART), dim3(64), 0, st, a);
   hipLaunchKernelGGL(vic_put_finish, dim3(nblk), dim3(64), 0, st, a);
   if (s >= 0)
@@ -1555,8 +1554,10 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
     }
     // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  The persistent profile
     // kernel fills every SIMD, so concurrent chunks mostly queue behind each other; two of them still hide each other's
-    // host round trips and thin tail rounds on a big domain (-3 % step time at 2.5 M HRUs, same-box A/B), more do not.
-    int nchunk = (nhru >= 500000) ? 2 : 1;
+    // host round trips and thin tail rounds on a big domain (-3 % step time at 2.5 M HRUs, same-box A/B x3), more do not.
+    // The default stays one chunk: with concurrent chunks the per-kernel durations of a profile overlap and stop adding up
+    // to the step time.
+    int nchunk = 1;
     if (const char* ev = getenv("VICGPU_CHUNKS")) nchunk = atoi(ev);
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 16) nchunk = 16;
