@@ -88,6 +88,7 @@ typedef struct {
   double Zsum_node[VIC_MAX_NODES], dz_node[VIC_MAX_NODES], alpha[VIC_MAX_NODES], beta[VIC_MAX_NODES],
          gamma[VIC_MAX_NODES], max_moist_node[VIC_MAX_NODES], expt_node[VIC_MAX_NODES], bubble_node[VIC_MAX_NODES];
   double AreaFract[VIC_MAX_BANDS], Tfactor[VIC_MAX_BANDS], Pfactor[VIC_MAX_BANDS], BandElev[VIC_MAX_BANDS];
+  int AboveTreeLine[VIC_MAX_BANDS];     /* COMPUTE_TREELINE result (read by put_data only) */
   double zwt_zwt[VIC_NLAYER + 2][VIC_MAX_ZWTVMOIST], zwt_moist[VIC_NLAYER + 2][VIC_MAX_ZWTVMOIST];
 } orc_soil;
 

@@ -492,6 +492,7 @@ int vicorc_set_domain(void *hv, int ncell, int nhru, const double *cp, const int
     }
     for (b = 0; b < Nb; b++) {
       s->AreaFract[b] = CPV(VICGPU_CP_BAND(CPB_AREAFRACT, b, Nn, Nb)); s->Tfactor[b] = CPV(VICGPU_CP_BAND(CPB_TFACTOR, b, Nn, Nb));
+      s->AboveTreeLine[b] = CPV(VICGPU_CP_BAND(CPB_ABOVETREELINE, b, Nn, Nb)) != 0;
       s->Pfactor[b] = CPV(VICGPU_CP_BAND(CPB_PFACTOR, b, Nn, Nb)); s->BandElev[b] = CPV(VICGPU_CP_BAND(CPB_BANDELEV, b, Nn, Nb));
     }
     for (l = 0; l < VIC_NLAYER + 2; l++)

@@ -74,8 +74,7 @@ int vicorc_put_data(void *hv, int rec, const double *forcing, const double *cell
       const orc_hru *u = &h->hru[h->cell_list[k]];
       if (orc_veg(&h->model, u->veg_index)[VL_OVERSTORY] != 0) bandCv[u->band] += u->Cv;
     }
-    /* AboveTreeLine is not part of the cell table (COMPUTE_TREELINE is an ingest option): factor 1 (:199-208) */
-    for (b = 0; b < Nb; b++) TreeAdjust[b] = 1.;
+    for (b = 0; b < Nb; b++) TreeAdjust[b] = sc->AboveTreeLine[b] ? 1. / (1. - bandCv[b]) : 1.;          /* :199-208 */
     if (rec >= 0) {                                                                 /* :229-256 */
 #define FV(var) forcing[((size_t)(var) * ns + NR) * nc + c]
       OD(AIR_TEMP, 0) = FV(VIC_F_AIR_TEMP); OD(DENSITY, 0) = FV(VIC_F_DENSITY); OD(LONGWAVE, 0) = FV(VIC_F_LONGWAVE);
@@ -99,7 +98,8 @@ int vicorc_put_data(void *hv, int rec, const double *forcing, const double *cell
       double ThisAreaFract, ThisTreeAdjust, AreaFactor, tmp_evap, tmp_cond1, tmp_cond2, rad_temp, tmp_fract, bandFactor;
       if (!(Cv > 0)) continue;
       ThisAreaFract = sc->AreaFract[band]; ThisTreeAdjust = TreeAdjust[band];
-      if (!(ThisAreaFract > 0.)) continue;                                          /* AboveTreeLine is 0: the tree-line test passes */
+      if (!(ThisAreaFract > 0. && (u->is_artificial_bare || (!sc->AboveTreeLine[band] || (sc->AboveTreeLine[band] && !overstory)))))
+        continue;                                                                   /* :289-290 */
       OD(ELEV_BAND, band) = (double)(float)sc->BandElev[band];
       if (HasVeg) cv_veg += Cv * 1. * ThisTreeAdjust; else cv_baresoil += Cv * 1. * ThisTreeAdjust;
       if (overstory) cv_overstory += Cv * 1. * ThisTreeAdjust;

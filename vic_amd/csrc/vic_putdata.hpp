@@ -14,7 +14,7 @@
 //                       water and energy balance errors and their bookkeeping (put_data.c:549-633).
 //   vic_put_aggregate   one lane = one cell x 32 rows: temporal aggregation (put_data.c:663-685).
 // Option subset as everywhere in this library: no lakes, Ndist = 1, SPATIAL_FROST / EXCESS_ICE off, MOISTFRACT and
-// ALMA_OUTPUT off; AboveTreeLine (COMPUTE_TREELINE, an ingest option) is taken as 0 -> TreeAdjustFactor = 1.
+// ALMA_OUTPUT off.  The tree-line adjustment factors (put_data.c:185-208) are derived once per domain (VIC_CPX_TREE_ROW).
 #pragma once
 #include "vic_types.hpp"
 #include "vicgpu_out.h"
@@ -71,18 +71,20 @@ enum { VOUT_AGG_SKIP = 3 };     // rows the aggregation kernel leaves alone (vic
 constexpr int PUT_NPART = 3, PUT_AGG_ROWS = 32;
 
 // what the three kernels share per HRU: whether put_data visits it and its factors
-struct PutHru { bool run, HasVeg, HasGlac, overstory; int band; double Cv, ThisAreaFract; };
+struct PutHru { bool run, HasVeg, HasGlac, overstory; int band; double Cv, ThisAreaFract, TreeAdjust; };
 VIC_DEV PutHru put_hru(const OArgs& a, const CellView& cv, int g) {
   const size_t nh = a.nhru;
   PutHru h;
   h.Cv = a.hpd[(size_t)HPD_CV * nh + g];
   h.band = a.hpi[(size_t)HPI_BAND * nh + g];
   h.ThisAreaFract = cv.band(CPB_AREAFRACT, h.band);
-  h.run = (h.Cv > 0) && (h.ThisAreaFract > 0.);
-  const bool is_glac = a.hpi[(size_t)HPI_IS_GLACIER * nh + g] != 0;
-  h.HasVeg = !(a.hpi[(size_t)HPI_IS_ARTIFICIAL_BARE * nh + g] != 0 || is_glac);
+  const bool is_glac = a.hpi[(size_t)HPI_IS_GLACIER * nh + g] != 0, art_bare = a.hpi[(size_t)HPI_IS_ARTIFICIAL_BARE * nh + g] != 0;
+  h.HasVeg = !(art_bare || is_glac);
   h.HasGlac = is_glac;
   h.overstory = a.veglib[(size_t)a.hpi[(size_t)HPI_VEG_INDEX * nh + g] * VL_NFIELD + VL_OVERSTORY] != 0.0;
+  const bool atl = cv.band(CPB_ABOVETREELINE, h.band) != 0.0;
+  h.TreeAdjust = cv.s(VIC_CPX_TREE_ROW(h.band, cv.Nn, cv.Nb));                       // put_data.c:199-208, derived with the domain
+  h.run = (h.Cv > 0) && (h.ThisAreaFract > 0.) && (art_bare || (!atl || (atl && !h.overstory)));   // :289-290
   return h;
 }
 
@@ -117,7 +119,7 @@ VIC_DEV void put_sum_part(const OArgs& a, int c) {
       const int g = a.cell_list[k];
       const PutHru h = put_hru(a, cv, g);
       if (!h.run) continue;
-      const double Cv = h.Cv, ThisTreeAdjust = 1.;
+      const double Cv = h.Cv, ThisTreeAdjust = h.TreeAdjust;
       const double swq = SD(SD_SNOW_SWQ);
       if (h.HasVeg) cv_veg += Cv * 1. * ThisTreeAdjust; else cv_baresoil += Cv * 1. * ThisTreeAdjust;
       if (h.overstory) cv_overstory += Cv * 1. * ThisTreeAdjust;
@@ -220,7 +222,7 @@ VIC_DEV void put_sum_part(const OArgs& a, int c) {
       const int g = a.cell_list[k];
       const PutHru h = put_hru(a, cv, g);
       if (!h.run) continue;
-      const double AreaFactor = h.Cv * 1. * 1.;
+      const double AreaFactor = h.Cv * h.TreeAdjust * 1.;
       if (o.FROZEN_SOIL) {
 #pragma unroll
         for (int l = 0; l < VIC_MAX_FRONTS; l++) {

@@ -110,7 +110,10 @@ struct VegLib {
 // vicgpu_set_domain): the factors of soil_conductivity (soil_conduction.c:7-105) that depend on the layer's soil only.
 enum { CPX_KDRY = 0, CPX_KSP, CPX_KWP, CPX_POROSITY, CPX_NFIELD };
 #define VIC_CPX_ROW(f, l, Nn, Nb) (VICGPU_CP_NROW(Nn, Nb) + (f) * VIC_NLAYER + (l))
-#define VIC_CPX_NROW(Nn, Nb) (VICGPU_CP_NROW(Nn, Nb) + CPX_NFIELD * VIC_NLAYER)
+// ... and put_data's tree-line adjustment factor of every band (put_data.c:185-208: a function of the HRU areas, the
+// vegetation classes and AboveTreeLine, all fixed with the domain)
+#define VIC_CPX_TREE_ROW(b, Nn, Nb) (VICGPU_CP_NROW(Nn, Nb) + CPX_NFIELD * VIC_NLAYER + (b))
+#define VIC_CPX_NROW(Nn, Nb) (VICGPU_CP_NROW(Nn, Nb) + CPX_NFIELD * VIC_NLAYER + (Nb))
 
 struct CellView {
   const double* __restrict__ cp;   // [CP_NROW + derived rows][ncell]

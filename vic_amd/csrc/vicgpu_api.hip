@@ -885,6 +885,23 @@ __global__ __launch_bounds__(256) void vic_derive_cell_params(double* cp, int nc
   }
 }
 
+// TreeAdjustFactor of put_data.c:185-208 for every band of every cell (lane = cell; once per vicgpu_set_domain)
+__global__ __launch_bounds__(64) void vic_derive_tree_adjust(double* cp, int ncell, int nhru, int Nn, int Nb, const int* cell_off, const int* cell_list,
+                                                             const int* hpi, const double* hpd, const double* veglib) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= ncell) return;
+  for (int b = 0; b < Nb; b++) {
+    double bandCv = 0;
+    for (int k = cell_off[c]; k < cell_off[c + 1]; k++) {          // hruList order, like the reference's sum
+      const int g = cell_list[k];
+      if (hpi[(size_t)HPI_BAND * nhru + g] != b) continue;
+      if (veglib[(size_t)hpi[(size_t)HPI_VEG_INDEX * nhru + g] * VL_NFIELD + VL_OVERSTORY] != 0.0) bandCv += hpd[(size_t)HPD_CV * nhru + g];
+    }
+    const bool atl = cp[(size_t)VICGPU_CP_BAND(CPB_ABOVETREELINE, b, Nn, Nb) * ncell + c] != 0.0;
+    cp[(size_t)VIC_CPX_TREE_ROW(b, Nn, Nb) * ncell + c] = atl ? 1. / (1. - bandCv) : 1.;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ test hook
 struct DArgs { Opt o; const double* cell_params; int ncell, fn, n; const double* in; double* out; };
 
@@ -2041,8 +2058,13 @@ int vicgpu_out_var_nelem(const vicgpu_options* opt, int id) {
 
 int vicgpu_put_data_config(vicgpu_ctx* c, int out_step_ratio) {
   if (!c || out_step_ratio < 1) return VICGPU_ERR_ARG;
-  if (!c->domain_ready) return VICGPU_ERR_STATE;
+  if (!c->domain_ready || !c->d_veglib) return VICGPU_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // the tree-line adjustment factor of every band (a function of the domain and the vegetation library's overstory flags)
+  hipLaunchKernelGGL(vic_derive_tree_adjust, dim3((c->ncell + 63) / 64), dim3(64), 0, c->stream, c->d_cp, c->ncell, c->nhru, c->opt.Nnode,
+                     c->opt.Nband, c->d_cell_off, c->d_cell_list, c->d_hpi, c->d_hpd, c->d_veglib);
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int r = 0;
   for (int v = 0; v < VOUT_NVAR; v++) {
