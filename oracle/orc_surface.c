@@ -490,7 +490,7 @@ static double orc_surf_energy_bal(double Ts, void *vctx) {
   return error;
 }
 
-/* calc_surf_energy_bal.c:7-692 (QUICK_SOLVE not supported).  Returns Tsurf or ORC_ERROR. */
+/* calc_surf_energy_bal.c:7-692.  Returns Tsurf or ORC_ERROR. */
 double orc_calc_surf_energy_bal(const orc_model *m, double Le, double LongUnderIn, double NetLongSnow, double NetShortGrnd,
                                 double NetShortSnow, double OldTSurf, double ShortUnderIn, double SnowAlbedo,
                                 double SnowLatent, double SnowLatentSub, double SnowSensible, double Tair, double VPDcanopy,
@@ -559,11 +559,33 @@ double orc_calc_surf_energy_bal(const orc_model *m, double Le, double LongUnderI
   if (m->opt.FULL_ENERGY) {
     if (INCLUDE_SNOW) { T_lower = energy->T[0] - ORC_SURF_DT; T_upper = 0.; }
     else { T_lower = 0.5 * (energy->T[0] + Tair) - ORC_SURF_DT; T_upper = 0.5 * (energy->T[0] + Tair) + ORC_SURF_DT; }
+    if (m->opt.QUICK_SOLVE && !m->opt.QUICK_FLUX) {
+      /* calc_surf_energy_bal.c:289-299: iterate on the nodes down to the thaw depth + 4 only (NOFLUX / EXP_TRANS are forced
+       * FALSE there, :298-309: this restatement is for runs that have them off anyway, vicgpu_create refuses the others) */
+      int tmpNnodes = 0;
+      for (nidx = Nnodes - 5; nidx >= 0; nidx--)
+        if (energy->T[nidx] >= 0 && energy->T[nidx + 1] < 0) tmpNnodes = nidx + 1;
+      if (tmpNnodes == 0) {
+        if (energy->T[0] <= 0 && energy->T[1] >= 0) tmpNnodes = Nnodes;
+        else tmpNnodes = 3;
+      } else tmpNnodes += 4;
+      c.Nnodes = tmpNnodes;
+    }
     Tsurf = orc_root_brent(T_lower, T_upper, orc_surf_energy_bal, &c);
     if (orc_is_error(Tsurf)) {
       if (m->opt.TFALLBACK) { Tsurf = Ts_old; Tsurf_fbflag = 1; Tsurf_fbcount++; }
       else return ORC_ERROR;
     }
+    if (Ts_old * Tsurf < 0 && m->opt.QUICK_SOLVE) {                                   /* :400-480: again on the whole column */
+      c.Nnodes = Nnodes;
+      c.Tsnow_surf = snow->surf_temp;              /* a fresh SurfEnergyBal object: by-value members restart */
+      Tsurf = orc_root_brent(T_lower, T_upper, orc_surf_energy_bal, &c);
+      if (orc_is_error(Tsurf)) {
+        if (m->opt.TFALLBACK) { Tsurf = Ts_old; Tsurf_fbflag = 1; Tsurf_fbcount++; }
+        else return ORC_ERROR;
+      }
+    }
+    c.Nnodes = Nnodes;
   } else Tsurf = Tair;
 
   /* the final evaluation uses a fresh SurfEnergyBal object (calc_surf_energy_bal.c:489-506): by-value members such as

@@ -102,6 +102,7 @@ void *vicref_create(const vicgpu_options *opt) {
   s.options.CORRPREC = opt->CORRPREC;
   s.options.NOFLUX = opt->NOFLUX;
   s.options.IMPLICIT = opt->IMPLICIT;
+  s.options.QUICK_SOLVE = opt->QUICK_SOLVE;
   s.options.EXP_TRANS = opt->EXP_TRANS;
   s.options.GRND_FLUX_TYPE = opt->GRND_FLUX_TYPE;
   s.options.TFALLBACK = opt->TFALLBACK;

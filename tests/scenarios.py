@@ -63,10 +63,18 @@ IMPLICIT_BRANCHES = {
     "implicit_noflux_n12": dict(kw=dict(FROZEN, IMPLICIT=1, NOFLUX=1, Nnode=12), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=10),
 }
 
+# QUICK_SOLVE (calc_surf_energy_bal.c:289-309, 400-480): the Tsurf iteration on the nodes above the thaw depth + 4, a second
+# iteration on the whole column when the surface changes sign, the final evaluation on the whole column
+QUICK_SOLVE_BRANCHES = {
+    "quick_solve": dict(kw=dict(FROZEN, QUICK_SOLVE=1), variant="fixed", ncell=4, ntile=3, nsteps=150, doy=95),
+    "quick_solve_winter": dict(kw=dict(FROZEN, QUICK_SOLVE=1, Nnode=12), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=330),
+    "quick_solve_glacier": dict(kw=dict(FROZEN, QUICK_SOLVE=1, Nband=2), variant="fixed", ncell=4, ntile=2, glacier=True, nsteps=80, doy=100),
+}
+
 
 def build(name, nsteps=None):
     """Domain + forcing of a scenario: returns (spec, d, f, sf, dmy)."""
-    sp = OPTION_BRANCHES[name] if name in OPTION_BRANCHES else IMPLICIT_BRANCHES[name]
+    sp = OPTION_BRANCHES.get(name) or IMPLICIT_BRANCHES.get(name) or QUICK_SOLVE_BRANCHES[name]
     opt = abi.default_options(**sp["kw"])
     d = domain.make_domain(sp["ncell"], opt, ntile=sp["ntile"], glacier_top_band=sp.get("glacier", False))
     n = nsteps or sp["nsteps"]

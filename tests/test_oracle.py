@@ -96,7 +96,7 @@ def test_oracle_vs_reference_side_by_side(case, oracle_lib, ref_available):
 _SC = __import__("tests.scenarios", fromlist=["x"])
 
 
-@pytest.mark.parametrize("name", list(_SC.OPTION_BRANCHES) + list(_SC.IMPLICIT_BRANCHES))
+@pytest.mark.parametrize("name", list(_SC.OPTION_BRANCHES) + list(_SC.QUICK_SOLVE_BRANCHES) + list(_SC.IMPLICIT_BRANCHES))
 def test_oracle_vs_reference_option_branches(name, oracle_lib, ref_available):
     """Every run-time option branch of the path (tests/scenarios.py: EXP_TRANS, NOFLUX, node counts, GRND_FLUX_TYPE,
     AERO_RESIST_CANSNOW, SNTHERM / SUN1999 / VIC_412, TFALLBACK off, forced solver failures, GLACIER_DYNAMICS): the oracle
