@@ -23,11 +23,11 @@
  * Option coverage: Nlayer = 3, DIST_PRCP = FALSE
  * (Ndist = 1, mu = 1), no lakes, no EXCESS_ICE / SPATIAL_FROST / SPATIAL_SNOW /
  * QUICK_FS / LOW_RES_MOIST / CLOSE_ENERGY (all compiled out in the reference,
- * user_def.h:36-92).  CORRPREC and IMPLICIT (finite-difference soil profile, node-array
- * freezing parameters: frozen_compat = 0) are implemented.  The options struct also
- * carries BLOWING and QUICK_SOLVE so that a binding passes the reference's settings
- * through unchanged: what the device code does not implement (see vicgpu_create) is
- * REJECTED with VICGPU_ERR_UNSUPPORTED, never silently replaced by another solver.
+ * user_def.h:36-92).  CORRPREC, IMPLICIT (finite-difference soil profile, node-array
+ * freezing parameters: frozen_compat = 0) and QUICK_SOLVE (with NOFLUX and EXP_TRANS off)
+ * are implemented.  The options struct also carries BLOWING so that a binding passes the
+ * reference's settings through unchanged: what the device code does not implement (see
+ * vicgpu_create) is REJECTED with VICGPU_ERR_UNSUPPORTED, never silently replaced.
  */
 #ifndef VICGPU_H_
 #define VICGPU_H_
@@ -101,7 +101,8 @@ typedef struct vicgpu_options {
   int IMPLICIT;             /* options.IMPLICIT: Newton-Raphson soil heat solver (frozen_soil.c:229-301, newt_raph_func_fast.c),
                                the explicit solver as its fallback; rejected with QUICK_FLUX or frozen_compat */
   int BLOWING;              /* options.BLOWING: blowing-snow sublimation (CalcBlowingSnow.c); rejected when set */
-  int QUICK_SOLVE;          /* options.QUICK_SOLVE (calc_surf_energy_bal.c:289-314, 400-475); rejected when set */
+  int QUICK_SOLVE;          /* options.QUICK_SOLVE (calc_surf_energy_bal.c:289-314, 400-475): ignored with QUICK_FLUX (as in the
+                               reference); rejected together with NOFLUX, EXP_TRANS or IMPLICIT */
   int NODE_SOLVER;          /* VIC_NODE_SOLVER_*: how the frozen-node heat balance (soil_thermal_eqn.c) is solved -- not a
                                reference option; BRENT replays root_brent.c's iteration, NEWTON converges to the same root */
   double wind_h;            /* global_param.wind_h (m) */

@@ -143,13 +143,14 @@ def assert_int_state_equal(io, ig, Nn, where):
 
 
 @pytest.mark.parametrize("name,solver", _with_solvers([(n, sp["kw"]) for n, sp in list(scenarios.OPTION_BRANCHES.items())
-                                                       + list(scenarios.IMPLICIT_BRANCHES.items())]))
+                                                       + list(scenarios.QUICK_SOLVE_BRANCHES.items()) + list(scenarios.IMPLICIT_BRANCHES.items())]))
 def test_teacher_forced_option_branches(name, solver, oracle_lib):
     """One case per run-time option branch of the device code (tests/scenarios.py; each is pinned oracle-vs-reference in
     tests/test_oracle.py): EXP_TRANS, NOFLUX, node counts 5/12/18 on the generic template, GRND_FLUX_TYPE, every
     AERO_RESIST_CANSNOW variant, SNTHERM, SUN1999, VIC_412, TFALLBACK off, forced solver failures (fallback flags and
     counters with TFALLBACK on, per-cell error bits with it off), GLACIER_DYNAMICS with zero-area glacier HRUs, and the
-    IMPLICIT soil heat solution (Newton iteration, explicit solver as its fallback)."""
+    QUICK_SOLVE (Tsurf iteration on the shortened column, second iteration after a sign change), and the IMPLICIT soil heat
+    solution (Newton iteration, explicit solver as its fallback)."""
     from vic_amd.api import Model
     sp, d, f, sf, dmy = scenarios.build(name, nsteps=36)
     d.opt.NODE_SOLVER = SOLVERS[solver]

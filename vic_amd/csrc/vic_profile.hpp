@@ -54,6 +54,7 @@ struct PArgs {
   int* count_zero;                   // segment counters [NBUCKET] of the list the following evaluation kernel appends to (cleared here)
   int* evalonly_zero;                // counter of HRUs whose next evaluation needs no solve (cleared here)
   int Nn, NOFLUX, EXP_TRANS, TFALLBACK;
+  const int* jl;                     // QUICK_SOLVE: [nhru] nodes 1 .. jl - 1 are solved (calc_surf_energy_bal.c:289-299), or null: all
 };
 
 // One solution record: T[Nn], {fbmask | ok << 32}, int fallback counts [Nn].  Every HRU keeps the records of its last
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
   const bool EXP_TRANS = a.EXP_TRANS != 0;
 
   bool have = false, sweeping = false, converged = false, ok = true, frozen_on = false;
-  int hru = 0, ps = 0, it = 1;
+  int hru = 0, ps = 0, it = 1, jl_lane = 0;
   unsigned fbmask = 0;
   int evcnt = 0;                                       // 1 once a node solver of this solve has fallen back (see below)
   double T[NN];
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
         hru = profile_pick(a, bcount, slot);
         const double* __restrict__ blk = a.pin + (size_t)hru * Nn * PREC;
         ps = a.pslot[hru];
+        jl_lane = a.jl ? a.jl[hru] : jlast;
         frozen_on = blk[PR_AT0] != 0.0;
         const double Ts = a.ts[hru];
 #pragma unroll
@@ -304,9 +306,10 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
           }
           bool failed;
           double newT;
-          if (j == 1) newT = node_visit<true, NEWTON>(sweeping, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
-          else newT = node_visit<false, NEWTON>(sweeping, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
-          if (sweeping) {
+          const bool swj = sweeping && j < jl_lane;          // QUICK_SOLVE: the lane's column ends earlier
+          if (j == 1) newT = node_visit<true, NEWTON>(swj, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
+          else newT = node_visit<false, NEWTON>(swj, frozen_on, EXP_TRANS, Kj, oldT, Tdn, Tup, T0j, failed);
+          if (swj) {
             if (failed) {
               if (a.TFALLBACK) {
                 // node fallback: T0 and a count.  The counters live in the solution record (rare path): the first event of a
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
       int cadd[NN];
 #pragma unroll
       for (int k = 0; k < NN; k++) T0v[k] = T0(k);
-      profile_finish<NN>(Nn, a.TFALLBACK != 0, converged, ok, fbmask, T, T0v, cadd);
+      profile_finish<NN>(a.jl ? jl_lane + 1 : Nn, a.TFALLBACK != 0, converged, ok, fbmask, T, T0v, cadd);
       double* __restrict__ rec = a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn);
       int* __restrict__ cnt = reinterpret_cast<int*>(rec + Nn + 1);
 #pragma unroll
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
 #define LS_REC() (a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn))
 #define LS_CNT(j) (reinterpret_cast<int*>(LS_REC() + Nn + 1)[j])
   bool have = false, sweeping = false, converged = false, ok = true, frozen_on = false;
-  int hru = 0, ps = 0, it = 1;
+  int hru = 0, ps = 0, it = 1, jl_lane = 0;
   unsigned fbmask = 0;
   const double* __restrict__ blk = a.pin;
   bool more = true;
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
         hru = profile_pick(a, bcount, slot);
         blk = a.pin + (size_t)hru * Nn * PREC;
         ps = a.pslot[hru];
+        jl_lane = a.jl ? a.jl[hru] : jlast;
         frozen_on = blk[PR_AT0] != 0.0;
         const double Ts = a.ts[hru];
 #pragma unroll
@@ -439,9 +443,10 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
           }
           bool failed;
           double newT;
-          if (j == 1) newT = node_visit<true, NEWTON>(sweeping, frozen_on, EXP_TRANS, K, oldT, Tdn, Tup, T0j, failed);
-          else newT = node_visit<false, NEWTON>(sweeping, frozen_on, EXP_TRANS, K, oldT, Tdn, Tup, T0j, failed);
-          if (sweeping) {
+          const bool swj = sweeping && j < jl_lane;          // QUICK_SOLVE: the lane's column ends earlier
+          if (j == 1) newT = node_visit<true, NEWTON>(swj, frozen_on, EXP_TRANS, K, oldT, Tdn, Tup, T0j, failed);
+          else newT = node_visit<false, NEWTON>(swj, frozen_on, EXP_TRANS, K, oldT, Tdn, Tup, T0j, failed);
+          if (swj) {
             if (failed) {
               if (a.TFALLBACK) { newT = T0j; fbmask |= (1u << j); LS_CNT(j) += 1; }
               else { ok = false; sweeping = false; }
@@ -461,9 +466,10 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
       }
     }
     if (have && !sweeping) {                        // this lane's item is through: finish it and free the lane
+      const int nq = a.jl ? jl_lane + 1 : Nn;      // the column this solve covered (QUICK_SOLVE: shorter)
       if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T(j)); Tlast == T0
 #pragma unroll 1
-        for (int k = 1; k < Nn - 1; k++) {
+        for (int k = 1; k < nq - 1; k++) {
           const double Tk = T(k), Tm = T(k - 1), Tp = T(k + 1), Lk = T0(k), Lm = T0(k - 1), Lp = T0(k + 1);
           if (Lm - Lk > 0 && Lp - Tk > 0 && (Tm - Tk) - (Lm - Lk) > 0 && (Tp - Tk) - (Lp - Lk) > 0) {
             T(k) = 0.5 * (Tm + Tp);
@@ -475,8 +481,8 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
       if (ok && !converged) {
         if (a.TFALLBACK) {
 #pragma unroll 1
-          for (int k = 0; k < Nn; k++) { T(k) = T0(k); LS_CNT(k) += 1; }
-          fbmask |= (Nn >= 32) ? 0xFFFFFFFFu : ((1u << Nn) - 1u);
+          for (int k = 0; k < nq; k++) { T(k) = T0(k); LS_CNT(k) += 1; }
+          fbmask |= (nq >= 32) ? 0xFFFFFFFFu : ((1u << nq) - 1u);
         } else ok = false;
       }
       double* __restrict__ rec = LS_REC();

@@ -528,7 +528,7 @@ VIC_DEV bool surface_fluxes(const Opt& o, const CellView& cv, const VegLib& vl, 
     PROF_T0(t_sf);
     while (sv.stage != SurfSolve::DONE) {
       const double fx = eb.eval(o, s3, sv.x, 0., 0.);
-      surf_solve_consume(o, sv, eb, fx);
+      surf_solve_consume(o, sv, eb, eb, fx);
     }
     PROF_ADD(3, t_sf);
     sf_sub_post<NN>(o, cv, vl, s3, fc, dmy, C, w, L, P, eb, sv, nullptr, nullptr, 0u);

@@ -220,7 +220,7 @@ struct SurfPost {
 // residual evaluation per call of surf_solve_consume: the same code runs inside a lane's loop (QUICK_FLUX) and across
 // launches of the evaluation kernel (finite-difference profile).
 struct SurfSolve {
-  enum { ROOT = 0, FINAL = 1, DONE = 2 };
+  enum { ROOT = 0, FINAL = 1, DONE = 2, ROOT_QUICK = 3 };   // ROOT_QUICK: QUICK_SOLVE's first iteration, on the shortened column
   Brent br;
   double x, Tsurf, snow_surf_temp, Ts_old, error;
   int stage, fbflag, fbcount, ok;
@@ -236,15 +236,16 @@ VIC_DEV void surf_solve_begin(const Opt& o, SurfSolve& sv, double T0, double Tai
     if (INCLUDE_SNOW) { T_lower = T0 - SURF_DT; T_upper = 0.; }
     else { T_lower = 0.5 * (T0 + Tair) - SURF_DT; T_upper = 0.5 * (T0 + Tair) + SURF_DT; }
     sv.br.start(T_lower, T_upper);
-    sv.stage = SurfSolve::ROOT; sv.x = sv.br.x;
+    sv.stage = (o.QUICK_SOLVE && !o.QUICK_FLUX) ? SurfSolve::ROOT_QUICK : SurfSolve::ROOT; sv.x = sv.br.x;
   } else {
     sv.br.start(0, 0);
     sv.Tsurf = Tair; sv.x = Tair; sv.stage = SurfSolve::FINAL;
   }
 }
 
-VIC_DEV void surf_solve_consume(const Opt& o, SurfSolve& sv, SurfEBMut& m, double fx) {
-  if (sv.stage == SurfSolve::ROOT) {
+// ec: the residual's constant inputs (QUICK_SOLVE's second iteration starts from the same bracket as the first)
+VIC_DEV void surf_solve_consume(const Opt& o, SurfSolve& sv, SurfEBMut& m, const SurfEBConst& ec, double fx) {
+  if (sv.stage == SurfSolve::ROOT || sv.stage == SurfSolve::ROOT_QUICK) {
     sv.br.advance(fx);
     if (sv.br.phase == Brent::DONE) {
       double Tsurf = sv.br.result;
@@ -252,8 +253,18 @@ VIC_DEV void surf_solve_consume(const Opt& o, SurfSolve& sv, SurfEBMut& m, doubl
         if (o.TFALLBACK) { Tsurf = sv.Ts_old; sv.fbflag = 1; sv.fbcount++; }
         else sv.ok = 0;
       }
-      sv.Tsurf = Tsurf; sv.x = Tsurf; sv.stage = SurfSolve::FINAL;
-      m.Tsnow_surf = sv.snow_surf_temp;        // the final evaluation starts from the stored pack temperature
+      if (sv.stage == SurfSolve::ROOT_QUICK && sv.ok && sv.Ts_old * Tsurf < 0) {
+        // the surface changes sign: iterate again on the whole column (calc_surf_energy_bal.c:400-480), a fresh object
+        double T_lower, T_upper;
+        if (ec.INCLUDE_SNOW) { T_lower = sv.Ts_old - SURF_DT; T_upper = 0.; }
+        else { T_lower = 0.5 * (sv.Ts_old + ec.Tair) - SURF_DT; T_upper = 0.5 * (sv.Ts_old + ec.Tair) + SURF_DT; }
+        sv.br.start(T_lower, T_upper);
+        sv.stage = SurfSolve::ROOT; sv.x = sv.br.x;
+        m.Tsnow_surf = sv.snow_surf_temp;
+      } else {
+        sv.Tsurf = Tsurf; sv.x = Tsurf; sv.stage = SurfSolve::FINAL;
+        m.Tsnow_surf = sv.snow_surf_temp;        // the final evaluation starts from the stored pack temperature
+      }
     } else sv.x = sv.br.x;
   } else {
     sv.error = fx;

@@ -83,6 +83,7 @@ struct KArgs {
   int* hkey;                        // [nhru] work-list segment of each HRU (number of frozen nodes)
   double* pimp;                     // IMPLICIT: the implicit solver's item blocks [nhru][Nn][PIMP]
   int* lastexp;                     // IMPLICIT: [nhru] record slot holding the flags of the root find's last explicit solve
+  int* jl;                          // QUICK_SOLVE: [nhru] end of the column the profile kernel solves
   int phase;                        // 0: start of the step; p >= 1: after the root finder of sub-step p - 1
 };
 
@@ -696,6 +697,16 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
       }
       a.ts[g] = sv.x;
       a.pslot[g] = 0;
+      if (o.QUICK_SOLVE) {
+        // calc_surf_energy_bal.c:289-299: the iteration solves the nodes down to the thaw depth + 4 only
+        int tmpNnodes = 0;
+#pragma unroll
+        for (int n = NN - 1; n >= 0; n--)
+          if (n <= Nn - 5 && w.nd.T[n] >= 0 && w.nd.T[(n + 1 < NN) ? n + 1 : n] < 0) tmpNnodes = n + 1;
+        if (tmpNnodes == 0) tmpNnodes = (w.nd.T[0] <= 0 && w.nd.T[1] >= 0) ? Nn : 3;
+        else tmpNnodes += 4;
+        a.jl[g] = ((sv.stage == SurfSolve::ROOT_QUICK) ? tmpNnodes : Nn) - 1;
+      }
       a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 0)] = NAN;      // no solve on record yet
       a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 1)] = NAN;
       a.hstate[g] = 1;
@@ -726,9 +737,10 @@ struct EArgs {
   const int* hpi;
   unsigned long long* ctx;
   size_t ctx_words;
-  const double* pout;
+  double* pout;
   int* pslot;
   double* ts;
+  int* jl;               // QUICK_SOLVE: [nhru] end of the column the profile kernel solves (null otherwise)
   int* hstate;
   int* list_next;        // NBUCKET segments of list_cap entries
   int* count_next;       // [NBUCKET]
@@ -770,7 +782,14 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
   if (sv.stage == SurfSolve::FINAL) sv.final_slot = slot;
   const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
-  surf_solve_consume(a.o, sv, eb, fx);
+  const bool was_quick = sv.stage == SurfSolve::ROOT_QUICK;
+  surf_solve_consume(a.o, sv, eb, eb, fx);
+  if (was_quick && sv.stage != SurfSolve::ROOT_QUICK) {
+    // QUICK_SOLVE: from here on the whole column is solved; the records of the shortened column are not its solutions
+    a.jl[g] = a.Nn - 1;
+    a.pout[(size_t)g * pout_hru_stride(a.Nn) + pout_key(a.Nn, 0)] = NAN;
+    a.pout[(size_t)g * pout_hru_stride(a.Nn) + pout_key(a.Nn, 1)] = NAN;
+  }
   bool need_solve = sv.stage != SurfSolve::DONE;
   if (sv.stage == SurfSolve::FINAL && !a.implicit) {
     // the root has been found: the final evaluation needs the profile at sv.x, which is on record if sv.x is one of the
@@ -1107,7 +1126,7 @@ struct vicgpu_ctx {
   bool fd = false;
   unsigned long long* d_ctx = nullptr;
   double *d_pin = nullptr, *d_ts = nullptr, *d_pout = nullptr;
-  int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr, *d_lastexp = nullptr;
+  int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr, *d_lastexp = nullptr, *d_jl = nullptr;
   double* d_pimp = nullptr;        // IMPLICIT only
   int profile_waves = 0;           // resident waves of the profile kernel
   bool node_newton = false;        // frozen-node root finder: safeguarded Newton instead of the reference's Brent iteration
@@ -1124,11 +1143,11 @@ struct vicgpu_ctx {
 static void free_domain(vicgpu_ctx* c) {
   void* ps[] = {c->d_cp, c->d_hpd, c->d_sd, c->d_flux, c->d_cell_out, c->d_accum, c->d_hpi, c->d_si, c->d_cell_off, c->d_cell_list,
                 c->d_hru_err, c->d_cell_err, c->d_ctx, c->d_pin, c->d_ts, c->d_pout, c->d_hstate, c->d_pslot, c->d_hkey,
-                c->d_out_data, c->d_out_agg, c->d_pb, c->d_rowagg, c->d_pimp, c->d_lastexp};
+                c->d_out_data, c->d_out_agg, c->d_pb, c->d_rowagg, c->d_pimp, c->d_lastexp, c->d_jl};
   for (void* p : ps) HIPIGN(hipFree(p));
   c->d_out_data = c->d_out_agg = c->d_pb = nullptr;
   c->d_rowagg = nullptr;
-  c->d_pimp = nullptr; c->d_lastexp = nullptr;
+  c->d_pimp = nullptr; c->d_lastexp = nullptr; c->d_jl = nullptr;
   c->put_on = false;
   for (FdChunk& ch : c->chunks) {
     HIPIGN(hipFree(ch.d_glist)); HIPIGN(hipFree(ch.d_list[0])); HIPIGN(hipFree(ch.d_list[1])); HIPIGN(hipFree(ch.d_count));
@@ -1238,13 +1257,13 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
   PArgs pa;
   pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.pslot = c->d_pslot; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
-  pa.TFALLBACK = c->o.TFALLBACK; pa.next = ch->d_count + CNT_CURSOR; pa.cap = ch->list_cap;
+  pa.TFALLBACK = c->o.TFALLBACK; pa.next = ch->d_count + CNT_CURSOR; pa.cap = ch->list_cap; pa.jl = c->d_jl;
   EArgs ea;
   ea.o = c->o; ea.ncell = c->ncell; ea.nhru = c->nhru; ea.Nn = Nn; ea.glist = ch->d_glist; ea.gcount = ch->gcount;
   ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
   ea.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
   ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + CNT_CURSOR; ea.evalonly = ch->d_count + CNT_EVALONLY;
-  ea.list_cap = ch->list_cap; ea.hkey = c->d_hkey; ea.implicit = c->o.IMPLICIT;
+  ea.list_cap = ch->list_cap; ea.hkey = c->d_hkey; ea.implicit = c->o.IMPLICIT; ea.jl = c->d_jl;
   ea.veglib = c->d_veglib; ea.forcing = ka.forcing; ea.month = ka.dmy.month;
   const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
   const int nsub = c->o.NF;
@@ -1397,7 +1416,11 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   if (opt->QUICK_FLUX && opt->Nnode != 3) return VICGPU_ERR_ARG;             // get_global_param.c:1151-1155
   if (opt->FROZEN_SOIL && opt->QUICK_FLUX) return VICGPU_ERR_ARG;            // get_global_param.c:376-381
   // options of the reference this library does not implement are refused, never silently replaced
-  if (opt->BLOWING || opt->QUICK_SOLVE) return VICGPU_ERR_UNSUPPORTED;
+  if (opt->BLOWING) return VICGPU_ERR_UNSUPPORTED;
+  // QUICK_SOLVE (calc_surf_energy_bal.c:289-309, 400-480; ignored with QUICK_FLUX like in the reference): the reference forces
+  // NOFLUX and EXP_TRANS off for the iteration and keeps whatever it last set for the final evaluation -- implemented for
+  // runs that have both off; not combined with IMPLICIT
+  if (opt->QUICK_SOLVE && !opt->QUICK_FLUX && (opt->NOFLUX || opt->EXP_TRANS || opt->IMPLICIT)) return VICGPU_ERR_UNSUPPORTED;
   // IMPLICIT (newt_raph_func_fast.c): the finite-difference soil profile with the node freezing parameters of the node
   // arrays; the reference as shipped reads the 3-element layer arrays out of bounds there (frozen_soil.c:283-284)
   if (opt->IMPLICIT && (opt->QUICK_FLUX || opt->frozen_compat)) return VICGPU_ERR_UNSUPPORTED;
@@ -1416,7 +1439,7 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   o.AERO_RESIST_CANSNOW = opt->AERO_RESIST_CANSNOW; o.SNOW_ALBEDO = opt->SNOW_ALBEDO; o.SNOW_DENSITY = opt->SNOW_DENSITY;
   o.TEMP_TH_TYPE = opt->TEMP_TH_TYPE; o.GLACIER_ID = opt->GLACIER_ID; o.GLACIER_DYNAMICS = opt->GLACIER_DYNAMICS;
   o.frozen_compat = opt->frozen_compat; o.nveg_types = opt->nveg_types; o.wind_h = opt->wind_h; o.CORRPREC = opt->CORRPREC;
-  o.IMPLICIT = opt->IMPLICIT;
+  o.IMPLICIT = opt->IMPLICIT; o.QUICK_SOLVE = (opt->QUICK_SOLVE && !opt->QUICK_FLUX) ? 1 : 0;
   if (hipSetDevice(device) != hipSuccess) { delete c; return VICGPU_ERR_HIP; }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess
@@ -1552,6 +1575,10 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
     HIPCHK(c, fill_on(c->stream, c->d_hstate, 0, sizeof(int) * nhru));
     HIPCHK(c, fill_on(c->stream, c->d_pin, 0, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, fill_on(c->stream, c->d_pout, 0, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
+    if (c->o.QUICK_SOLVE) {
+      HIPCHK(c, hipMalloc(&c->d_jl, sizeof(int) * nhru));
+      HIPCHK(c, fill_on(c->stream, c->d_jl, 0, sizeof(int) * nhru));
+    }
     if (c->o.IMPLICIT) {
       HIPCHK(c, hipMalloc(&c->d_pimp, sizeof(double) * (size_t)Nn * PIMP * nhru));
       HIPCHK(c, hipMalloc(&c->d_lastexp, sizeof(int) * nhru));
@@ -1827,7 +1854,7 @@ int vicgpu_step(vicgpu_ctx* c, int step0, int nsteps) {
   ka.veglib = c->d_veglib; ka.cell_params = c->d_cp; ka.hpi = c->d_hpi; ka.hpd = c->d_hpd;
   ka.sd = c->d_sd; ka.si = c->d_si; ka.flux = c->d_flux; ka.hru_err = c->d_hru_err;
   ka.glist = nullptr; ka.gcount = c->nhru;
-  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.pslot = c->d_pslot; ka.hstate = c->d_hstate; ka.hkey = c->d_hkey; ka.pimp = c->d_pimp; ka.lastexp = c->d_lastexp; ka.list = nullptr; ka.count = nullptr; ka.list_cap = 0;
+  ka.ctx = c->d_ctx; ka.pin = c->d_pin; ka.ts = c->d_ts; ka.pout = c->d_pout; ka.pslot = c->d_pslot; ka.hstate = c->d_hstate; ka.hkey = c->d_hkey; ka.pimp = c->d_pimp; ka.lastexp = c->d_lastexp; ka.jl = c->d_jl; ka.list = nullptr; ka.count = nullptr; ka.list_cap = 0;
   ka.phase = 0;
   CArgs& ca = plan.ca;
   ca.ncell = c->ncell; ca.nhru = c->nhru; ca.c0 = 0; ca.ccount = c->ncell;
