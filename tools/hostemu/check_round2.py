@@ -1,6 +1,6 @@
 """The round-2 entry points through the sanitizer build of the device code: put_data (vic_put_sum / _finish / _aggregate),
-state records, forcing prefetch / swap with the on-device derivation, and the IMPLICIT profile kernel with its explicit
-fall-back.  Run by tests/test_hostemu_sanitizers.py (ASan runtime preloaded, VICGPU_LIB = the host build)."""
+state records, forcing prefetch / swap with the on-device derivation, the IMPLICIT profile kernel with its explicit
+fall-back, and QUICK_SOLVE (per-lane column end in the profile kernel).  Run by tests/test_hostemu_sanitizers.py (ASan runtime preloaded, VICGPU_LIB = the host build)."""
 import os, sys
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -58,8 +58,8 @@ def streaming():
     return rel_diff(f[3], fg, 1e-9).max()
 
 
-def implicit(nsteps):
-    sp, d, f, sf, dmy = scenarios.build("implicit_spring", nsteps=nsteps)
+def implicit(nsteps, name="implicit_spring"):
+    sp, d, f, sf, dmy = scenarios.build(name, nsteps=nsteps)
     sd0, si0 = init_state.initial_state(d, f[0])
     orc = pyref.OracleModel(d); orc.set_state(sd0, si0)
     dev = Model(d); dev.push_forcing(f, sf, dmy)
@@ -84,6 +84,8 @@ def main():
     print("hostemu streaming: worst rel diff %.3e" % w, flush=True); ok = ok and w < 1e-12
     w = implicit(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
     print("hostemu implicit: worst rel diff %.3e" % w, flush=True); ok = ok and w < 1e-3
+    w = implicit(3, "quick_solve")
+    print("hostemu quick_solve: worst rel diff %.3e" % w, flush=True); ok = ok and w < 1e-6
     return 0 if ok else 1
 
 
