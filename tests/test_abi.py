@@ -64,3 +64,23 @@ def test_create_fails_loudly_without_gpu():
     d = domain.make_domain(4, opt)
     with pytest.raises(api.VicGpuError):
         api.Model(d)
+
+
+def test_kernel_resource_limits_hold():
+    """vic_amd/build.py records the compiler's per-kernel register / scratch figures at every build and refuses a build in
+    which a kernel with a designed register budget spills (RESOURCE_LIMITS): the table exists, names every kernel family and
+    passes the check."""
+    import os
+    from vic_amd import build as vb
+    vb.build(force=False)
+    path = os.path.splitext(vb.OUT)[0] + ".resources.txt"
+    if not os.path.exists(path):
+        vb.build(force=True)
+    rows = [l.split() for l in open(path).read().splitlines()[1:]]
+    names = " ".join(r[0] for r in rows)
+    for k in ("vic_surf_eval", "vic::vic_profile_solve_reg<10,", "vic_fd_stage<10,", "vic_hru_step<3,", "vic::vic_put_sum", "vic_profile_solve_implicit"):
+        assert k in names, k
+    table = [(" ".join(r[:-7]),) + tuple(r[-7:]) for r in rows]
+    assert vb.check_resources(table) == []
+    bad = [("vic_surf_eval", "256", "0", "106", "548", "152", "55", "2")]
+    assert vb.check_resources(bad), "the check must catch a spilling evaluation kernel"

@@ -33,13 +33,78 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Build-time resource check (hipcc -Rpass-analysis=kernel-resource-usage, written next to the library): the kernels whose
+# register budget is part of their design must not spill behind one's back -- a few hundred bytes of scratch in the evaluation
+# kernel cost 5 ms per step twice this round.  Limits are per kernel name prefix: (max VGPRs, max scratch bytes).
+RESOURCE_LIMITS = {
+    "vic_surf_eval": (256, 0),
+    "vic::vic_profile_solve_reg<10": (256, 128),
+    "vic::vic_profile_solve_lockstep": (256, 0),
+    "vic::vic_put_": (256, 0),
+    "vic_cell_reduce": (128, 0),
+}
+
+
+def parse_resources(remarks):
+    """{kernel symbol: {field: value}} from the compiler's kernel-resource-usage remarks."""
+    import re
+    kern, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: .*?Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1); kern[cur] = {}; continue
+        m = re.search(r"remark: .*?\s{2,}([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass", line)
+        if m and cur:
+            kern[cur][m.group(1).strip()] = m.group(2)
+    return kern
+
+
+def resource_table(kern):
+    import re
+    names = list(kern)
+    dem = subprocess.run(["c++filt"] + names, stdout=subprocess.PIPE, text=True).stdout.splitlines() if names else []
+    rows = []
+    for name, dm in zip(names, dem):
+        v = kern[name]
+        short = re.sub(r"\(.*", "", dm).replace("void ", "")
+        rows.append((short, v.get("VGPRs", "?"), v.get("AGPRs", "?"), v.get("TotalSGPRs", "?"), v.get("ScratchSize", "?"),
+                     v.get("VGPRs Spill", "?"), v.get("SGPRs Spill", "?"), v.get("Occupancy", "?")))
+    rows.sort()
+    return rows
+
+
+def check_resources(rows):
+    """List of violations of RESOURCE_LIMITS."""
+    bad = []
+    for r in rows:
+        for prefix, (max_vgpr, max_scratch) in RESOURCE_LIMITS.items():
+            if r[0].startswith(prefix):
+                try:
+                    if int(r[1]) > max_vgpr or int(r[4]) > max_scratch:
+                        bad.append("%s: %s VGPRs, %s B scratch (limit %d / %d)" % (r[0], r[1], r[4], max_vgpr, max_scratch))
+                except ValueError:
+                    pass
+    return bad
+
+
 def build(force=False, extra=(), verbose=False, out=OUT):
     if not force and out == OUT and not needs_build():
         return OUT
-    cmd = [HIPCC] + FLAGS + list(extra) + [SRC, "-o", out]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-Rpass-analysis=kernel-resource-usage", SRC, "-o", out]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout)
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+    rows = resource_table(parse_resources(p.stdout))
+    with open(os.path.splitext(out)[0] + ".resources.txt", "w") as f:
+        f.write("%-62s %5s %5s %5s %8s %6s %6s %5s\n" % ("kernel", "VGPR", "AGPR", "SGPR", "scratchB", "vspill", "sspill", "occ"))
+        for r in rows:
+            f.write("%-62s %5s %5s %5s %8s %6s %6s %5s\n" % ((r[0][:62],) + r[1:]))
+    bad = check_resources(rows)
+    if bad and not extra:            # tuning variants (extra flags) are measured, not policed
+        raise RuntimeError("kernel resource limits exceeded (vic_amd/build.py RESOURCE_LIMITS):\n  " + "\n  ".join(bad))
     return OUT
 
 
