@@ -244,6 +244,45 @@ VicGpuBinding::VicGpuBinding(const ProgramState *st, std::vector<cell_info_struc
 VicGpuBinding::~VicGpuBinding() { if (ctx) vicgpu_destroy(ctx); }
 const char *VicGpuBinding::error() const { return ctx ? vicgpu_last_error(ctx) : "vicgpu_create / set_domain failed"; }
 
+int VicGpuBinding::enable_put_data(int out_step_ratio) {
+  if (!ctx) return VICGPU_ERR_STATE;
+  // the per-HRU values put_data reads that live outside the state tables: here the frost / thaw fronts of
+  // initialize_model_state (energy.fdepth / tdepth); everything else is rewritten by the first step
+  VicGpuTables &t = tables;
+  std::vector<double> flux((size_t)FX_NROW * t.nhru, 0.0);
+  for (int g = 0; g < t.nhru; g++) {
+    const HRU &u = cells[t.hru_cell[g]].prcp.hruList[t.hru_pos[g]];
+    for (int l = 0; l < VIC_MAX_FRONTS; l++) {
+      flux[(size_t)(FX_FDEPTH0 + l) * t.nhru + g] = u.energy.fdepth[l];
+      flux[(size_t)(FX_TDEPTH0 + l) * t.nhru + g] = u.energy.tdepth[l];
+    }
+    for (int l = 0; l < 3; l++) flux[(size_t)(FX_ZWTL0 + l) * t.nhru + g] = u.cell[WET].layer[l].zwt;
+    flux[(size_t)FX_AERO_RESIST_SURFACE * t.nhru + g] = u.cell[WET].aero_resist.surface;
+    flux[(size_t)FX_AERO_RESIST_OVERSTORY * t.nhru + g] = u.cell[WET].aero_resist.overstory;
+  }
+  int r = vicgpu_set_fluxes(ctx, flux.data());
+  if (r == VICGPU_OK) r = vicgpu_put_data_config(ctx, out_step_ratio);
+  if (r == VICGPU_OK) r = vicgpu_put_data_init(ctx);
+  return r;
+}
+
+int VicGpuBinding::outputs(const std::vector<std::string> &names, std::vector<float> &out, bool reset) {
+  if (!ctx) return VICGPU_ERR_STATE;
+  vicgpu_options opt;
+  vicgpu_binding_options(state, &opt);
+  std::vector<int> ids;
+  int rows = 0;
+  for (size_t i = 0; i < names.size(); i++) {
+    const int id = vicgpu_out_var_id(names[i].c_str());
+    if (id < 0) return VICGPU_ERR_ARG;
+    ids.push_back(id);
+    rows += vicgpu_out_var_nelem(&opt, id);
+  }
+  out.assign((size_t)rows * cells.size(), 0.f);
+  const int r = vicgpu_get_outputs(ctx, (int)ids.size(), ids.data(), out.data(), reset ? 1 : 0);
+  return r == VICGPU_OK ? rows : r;
+}
+
 int VicGpuBinding::run(int rec0, int nrec, const dmy_struct *dmy) {
   if (!ctx) return VICGPU_ERR_STATE;
   const int ns = state->NR + 1;

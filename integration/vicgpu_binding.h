@@ -5,6 +5,7 @@
 // reference structs, against the reference's own full_energy on a second copy of the same cells.
 #ifndef VICGPU_BINDING_H_
 #define VICGPU_BINDING_H_
+#include <string>
 #include <vector>
 #include "vicNl.h"
 #include "vicgpu.h"
@@ -44,8 +45,14 @@ public:
   ~VicGpuBinding();
   bool ok() const { return ctx != NULL; }
   const char *error() const;
+  // put_data on the device (dist_prec.c:167): call once before the first run(); out_step_ratio = out_dt / dt.  The per-HRU
+  // values initialize_model_state left outside the state tables (frost fronts, ...) go with it.
+  int enable_put_data(int out_step_ratio);
   // records [rec0, rec0 + nrec) of cell.atmos[] with their dates; returns 0 or a VICGPU_ERR_*
   int run(int rec0, int nrec, const dmy_struct *dmy);
+  // OutputData.aggdata of the named variables ("OUT_RUNOFF", ...) as write_data_all_cells wants them: float
+  // [sum nelem][ncell], cells in the order of the vector; reset = vicNl.c:599-606.  Returns the number of rows or < 0.
+  int outputs(const std::vector<std::string> &names, std::vector<float> &out, bool reset);
   // device state -> the cells' HRU structs; per-cell ERROR flags (vicNl.c:545-559) into flags[ncell] if given
   int finish(int *flags);
   VicGpuTables tables;

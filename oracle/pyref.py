@@ -203,18 +203,23 @@ class RefModel(_Model):
                  _d(t["sd"]), _i(t["si"]), ctypes.byref(t["opt"])) == 0
         return t
 
-    def run_through_binding(self, forcing, snowflag, dmy, device=0):
+    def run_through_binding(self, forcing, snowflag, dmy, device=0, out_names=(), out_step_ratio=1, out_rows=0):
         """All steps through VicGpuBinding (the reference-side binding) on the GPU; libvicgpu.so is loaded globally first so
-        that the binding's vicgpu_* calls resolve.  Returns the per-cell error flags."""
+        that the binding's vicgpu_* calls resolve.  out_names: put_data runs on the device as well and the aggregates of
+        those variables come back (float32 [out_rows][ncell]).  Returns (per-cell error flags, outputs or None)."""
         from vic_amd import api
         ctypes.CDLL(os.environ.get("VICGPU_LIB", api.LIB_PATH), mode=os.RTLD_GLOBAL | os.RTLD_NOW)
         forcing = np.ascontiguousarray(forcing); snowflag = np.ascontiguousarray(snowflag); dmy = np.ascontiguousarray(dmy, dtype=np.int32)
         flags = np.zeros(self.dom.ncell, dtype=np.int32)
+        outs = np.zeros((max(out_rows, 1), self.dom.ncell), dtype=np.float32)
+        names = (ctypes.c_char_p * max(len(out_names), 1))(*[n.encode() for n in out_names])
         f = self.lib.vicref_run_through_binding; f.restype = ctypes.c_int
-        f.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte), _ip, ctypes.c_int, _ip]
-        rc = f(self.h, forcing.shape[0], _d(forcing), snowflag.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _i(dmy), int(device), _i(flags))
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte), _ip, ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int,
+                      ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float)]
+        rc = f(self.h, forcing.shape[0], _d(forcing), snowflag.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _i(dmy), int(device), _i(flags),
+               int(out_step_ratio), len(out_names), names, outs.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
         assert rc == 0, "binding returned %d" % rc
-        return flags
+        return flags, (outs if out_names else None)
 
     def state_stream(self):
         """The reference's own state-file stream of every cell (processCellForStateFile into a memory back-end):

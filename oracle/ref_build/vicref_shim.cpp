@@ -483,9 +483,10 @@ int vicref_binding_tables(void *hv, double *veglib, double *cell_params, int *hp
 /* nsteps records through VicGpuBinding (libvicgpu.so must be loaded in the process: the vicgpu_* symbols bind lazily): the
  * cells get an atmos[] array of nsteps records like the one initialize_atmos builds, the binding replaces the cell loop of
  * vicNl.c:506-593, and the device state ends up back in the cells' HRU structs.  frozen_compat / node_solver: the two
- * vicgpu_options fields that are not reference options.  Returns 0, or 100 + the binding's error, flags[ncell] = ERROR flags. */
+ * vicgpu_options fields that are not reference options.  nout > 0: put_data runs on the device too and the aggregates of the
+ * named variables come back as the writer's float table.  Returns 0, or 100 + the binding's error, flags[ncell] = ERROR flags. */
 int vicref_run_through_binding(void *hv, int nsteps, const double *forcing, const unsigned char *snowflag, const int *dmyv, int device,
-                               int *flags) {
+                               int *flags, int out_step_ratio, int nout, const char *const *out_names, float *outputs) {
   vicref_handle *h = (vicref_handle *)hv;
   const size_t ns = h->NR + 1, nc = h->ncell;
   std::vector<atmos_data_struct *> saved(h->ncell);
@@ -512,7 +513,14 @@ int vicref_run_through_binding(void *hv, int nsteps, const double *forcing, cons
     /* the two fields of vicgpu_options that are not options of the reference come from the harness's own options */
     VicGpuBinding b(&h->state, h->cells, device, h->opt.frozen_compat, h->opt.NODE_SOLVER);
     if (!b.ok()) rc = 100;
+    if (!rc && nout > 0) { int r = b.enable_put_data(out_step_ratio); if (r) rc = 100 - r; }
     if (!rc) { int r = b.run(0, nsteps, dmy.data()); if (r) rc = 100 - r; }
+    if (!rc && nout > 0) {          /* the aggregates of the output interval that ends with the last record */
+      std::vector<std::string> names(out_names, out_names + nout);
+      std::vector<float> o;
+      int r = b.outputs(names, o, true);
+      if (r < 0) rc = 100 - r; else memcpy(outputs, o.data(), sizeof(float) * o.size());
+    }
     if (!rc) { int r = b.finish(flags); if (r) rc = 100 - r; }
   }
   for (int c = 0; c < h->ncell; c++) {

@@ -94,11 +94,19 @@ def test_reference_runs_through_the_binding(case, oracle_lib, ref_available):
         if glacier:
             sd0[C["SD_GLAC_CUM_MASS_BALANCE"], d.hru_iparams[C["HPI_IS_GLACIER"]] != 0] = 0.0
             m.set_state(sd0, si0)
+    # the reference's own put_data next to its own steps; the device's put_data behind the binding
+    outs = ["OUT_RUNOFF", "OUT_BASEFLOW", "OUT_EVAP", "OUT_SWE", "OUT_SOIL_MOIST", "OUT_PREC", "OUT_SWE_BAND"]
+    a.put_data(-1); a.reset_agg()
     for s in range(nsteps):
         fr, cr, er = a.step(f[s], sf[s], dmy[s])
         assert er.sum() == 0
-    flags = b.run_through_binding(f, sf, dmy)
+        a.put_data(s, f[s], cr, nsteps)
+    want = np.concatenate([a.get_output(n, True) for n in outs]).astype(np.float32)
+    flags, got = b.run_through_binding(f, sf, dmy, out_names=outs, out_step_ratio=nsteps, out_rows=want.shape[0])
     assert flags.sum() == 0
+    from tests.util import rel_diff
+    wo = rel_diff(want, got, 1e-4).max()
+    assert wo < 1e-5, "aggregated outputs: the reference's put_data vs the device's behind the binding: %.3e" % wo
     (sa, ia), (sb, ib) = a.get_state(), b.get_state()
     sa[C["SD_ERROR"]] = 0; sb[C["SD_ERROR"]] = 0
     # free-running: near-zero node ice contents amplify the last bits of the node temperatures (tests/test_gpu_parity.py), so
