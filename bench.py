@@ -352,7 +352,7 @@ def main():
                        "node_solver": args.node_solver,
                        ("strict_replay_ms_per_step" if args.node_solver == "newton" else "newton_ms_per_step"): other_ms,
                        "streamed_raw_forcing_ms_per_step": stream_ms,
-                       "put_data": "on device every step (vic_put_data), out_step_ratio %d" % OUT_STEP_RATIO,
+                       "put_data": "on device every step (vic_put_sum / _finish / _aggregate), out_step_ratio %d" % OUT_STEP_RATIO,
                        "output_table": "%s as float32 [%d][%d]" % (",".join(OUT_VARS), full.shape[0], full.shape[1]),
                        "cells_with_error_flags": nerr, "output_gather_ms": gather_ms,
                        "mean_runoff_mm_per_step": float(full[row["OUT_RUNOFF"]].mean() / max(1, K)),
