@@ -138,6 +138,8 @@ template <int NN> constexpr size_t ctx_words() { return CO_W + sizeof(WCarry<NN>
 constexpr size_t CW_L_HEAD = offsetof(SubLoop, st_AlbedoOver) / 8;
 // SurfEBMut: the fields an evaluation reads back, then the pure outputs (parked by the final evaluation only)
 constexpr size_t CW_EBM_FEED = offsetof(SurfEBMut, Tnew2) / 8;
+// SurfSolve: the Brent state and the abscissa (rewritten by every evaluation), then the rest
+constexpr size_t CW_SV_ITER = offsetof(SurfSolve, Tsurf) / 8;
 
 template <class T>
 VIC_DEV void ctx_put_words(const CtxRef& r, size_t word0, const T& v, int first, int last) {
@@ -783,6 +785,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   if (sv.stage == SurfSolve::FINAL) sv.final_slot = slot;
   const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
   const bool was_quick = sv.stage == SurfSolve::ROOT_QUICK;
+  const int stage_before = sv.stage;
   surf_solve_consume(a.o, sv, eb, eb, fx);
   if (was_quick && sv.stage != SurfSolve::ROOT_QUICK) {
     // QUICK_SOLVE: from here on the whole column is solved; the records of the shortened column are not its solutions
@@ -798,7 +801,10 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
     if (rec[pout_key(a.Nn, slot)] == sv.x) { sv.final_slot = slot; sv.on_record = 1; need_solve = false; }
     else if (rec[pout_key(a.Nn, slot ^ 1)] == sv.x) { sv.final_slot = slot ^ 1; sv.on_record = 1; need_solve = false; }
   }
-  ctx_put(cx, CO_SV, sv);
+  // while the Brent iteration goes on only its own state and the next abscissa change: the tail of SurfSolve (result,
+  // flags, stage, record bookkeeping) is written when it does
+  if (sv.stage == stage_before && (sv.stage == SurfSolve::ROOT || sv.stage == SurfSolve::ROOT_QUICK)) ctx_put_words(cx, CO_SV, sv, 0, (int)CW_SV_ITER);
+  else ctx_put(cx, CO_SV, sv);
   ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, (int)CW_EBM_FEED);
   if (sv.stage == SurfSolve::DONE) ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), (int)CW_EBM_FEED, (int)CW_EBM);
   if (sv.stage == SurfSolve::DONE) a.hstate[g] = 2;
