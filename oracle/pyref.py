@@ -188,6 +188,15 @@ class RefModel(_Model):
             out[name.value.decode()] = (v, ne.value, ag.value)
         return out
 
+    def get_cell_params(self):
+        """The cell table as the reference holds it after initialize_model_state: the node geometry / node constants are
+        recomputed there (set_node_parameters, soil_conduction.c:142-303) and may differ from the generator's in the last bit."""
+        from vic_amd import abi
+        out = np.zeros((abi.cp_nrow(self.dom.opt.Nnode, self.dom.opt.Nband), self.dom.ncell))
+        f = self.lib.vicref_get_cell_params; f.restype = ctypes.c_int; f.argtypes = [ctypes.c_void_p, _dp]
+        assert f(self.h, _d(out)) == 0
+        return out
+
     def binding_tables(self):
         """What integration/vicgpu_binding.cpp packs from the harness's reference structs: dict of its tables (its own HRU
         numbering) + the vicgpu_options it derives from ProgramState."""

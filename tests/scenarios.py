@@ -74,7 +74,7 @@ QUICK_SOLVE_BRANCHES = {
 
 def build(name, nsteps=None):
     """Domain + forcing of a scenario: returns (spec, d, f, sf, dmy)."""
-    sp = OPTION_BRANCHES.get(name) or IMPLICIT_BRANCHES.get(name) or QUICK_SOLVE_BRANCHES[name]
+    sp = OPTION_BRANCHES.get(name) or IMPLICIT_BRANCHES.get(name) or QUICK_SOLVE_BRANCHES.get(name) or RANDOM_COMBINATIONS[name]
     opt = abi.default_options(**sp["kw"])
     d = domain.make_domain(sp["ncell"], opt, ntile=sp["ntile"], glacier_top_band=sp.get("glacier", False))
     n = nsteps or sp["nsteps"]
@@ -93,3 +93,48 @@ def build(name, nsteps=None):
         cell = d.hru_iparams[C["HPI_CELL"]]
         d.hru_dparams[C["HPD_CV"], isg & (cell % 2 == 0)] = 0.0
     return sp, d, f, sf, dmy
+
+
+def random_combinations(n=14, seed=2026):
+    """Seeded random combinations of the run-time options (valid ones: get_global_param.c:376-381, 1151-1155 and what
+    vicgpu_create accepts), so that interactions between branches are pinned too, not only each branch on its own.
+    Returns [(name, spec)] in the format of OPTION_BRANCHES."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        frozen = bool(rng.integers(0, 2)) or k % 3 == 0
+        kw = dict(FULL_ENERGY=1)
+        if frozen:
+            kw.update(FROZEN_SOIL=1, frozen_compat=0, Nnode=int(rng.choice([5, 8, 10, 12, 18])), NOFLUX=int(rng.integers(0, 2)),
+                      EXP_TRANS=int(rng.integers(0, 2)))
+            mode = rng.integers(0, 4)
+            if mode == 1 and kw["Nnode"] <= 18:
+                kw["IMPLICIT"] = 1
+            elif mode == 2 and not kw["NOFLUX"] and not kw["EXP_TRANS"]:
+                kw["QUICK_SOLVE"] = 1
+        elif rng.integers(0, 4) == 0:
+            kw = dict(FULL_ENERGY=0, dt=int(rng.choice([3, 24])), snow_step=3)
+        kw["Nband"] = int(rng.integers(1, 4))
+        kw["GRND_FLUX_TYPE"] = int(rng.choice([C["VIC_GF_406"], C["VIC_GF_410"], C["VIC_GF_FULL"]]))
+        kw["AERO_RESIST_CANSNOW"] = int(rng.choice([C["VIC_AR_406"], C["VIC_AR_406_LS"], C["VIC_AR_406_FULL"], C["VIC_AR_410"], C["VIC_AR_COMBO"]]))
+        kw["SNOW_DENSITY"] = int(rng.integers(0, 2)); kw["SNOW_ALBEDO"] = int(rng.integers(0, 2)); kw["TEMP_TH_TYPE"] = int(rng.integers(0, 2))
+        kw["CORRPREC"] = int(rng.integers(0, 2)); kw["TFALLBACK"] = int(rng.integers(0, 4) > 0)
+        glacier = bool(rng.integers(0, 3) == 0) and kw["Nband"] > 1
+        if glacier:
+            kw["GLACIER_DYNAMICS"] = int(rng.integers(0, 2))
+        out.append(("combo%02d" % k, dict(kw=kw, variant="fixed" if kw.get("FROZEN_SOIL") else "plain", ncell=5, ntile=2, glacier=glacier,
+                                          nsteps=24, doy=int(rng.choice([20, 95, 200, 330])))))
+    return out
+
+
+RANDOM_COMBINATIONS = dict(random_combinations())
+
+
+def all_scenarios():
+    """Every scenario name, ordered for a single test process: the IMPLICIT ones last and by increasing number of unknowns
+    (see IMPLICIT_BRANCHES: left-overs in the patched reference's static work arrays)."""
+    every = dict(OPTION_BRANCHES); every.update(QUICK_SOLVE_BRANCHES); every.update(RANDOM_COMBINATIONS); every.update(IMPLICIT_BRANCHES)
+    plain = [n for n, sp in every.items() if not sp["kw"].get("IMPLICIT")]
+    imp = sorted([n for n, sp in every.items() if sp["kw"].get("IMPLICIT")],
+                 key=lambda n: every[n]["kw"].get("Nnode", 10) - (1 if every[n]["kw"].get("NOFLUX") else 2))
+    return plain + imp, every

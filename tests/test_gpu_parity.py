@@ -142,8 +142,7 @@ def assert_int_state_equal(io, ig, Nn, where):
             where, len(bad), names.get(int(r), "node row "), "" if int(r) in names else int(r) - C["SI_NSCALAR"], c, io[r, c], ig[r, c]))
 
 
-@pytest.mark.parametrize("name,solver", _with_solvers([(n, sp["kw"]) for n, sp in list(scenarios.OPTION_BRANCHES.items())
-                                                       + list(scenarios.QUICK_SOLVE_BRANCHES.items()) + list(scenarios.IMPLICIT_BRANCHES.items())]))
+@pytest.mark.parametrize("name,solver", _with_solvers([(n, scenarios.all_scenarios()[1][n]["kw"]) for n in scenarios.all_scenarios()[0]]))
 def test_teacher_forced_option_branches(name, solver, oracle_lib):
     """One case per run-time option branch of the device code (tests/scenarios.py; each is pinned oracle-vs-reference in
     tests/test_oracle.py): EXP_TRANS, NOFLUX, node counts 5/12/18 on the generic template, GRND_FLUX_TYPE, every

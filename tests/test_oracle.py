@@ -96,12 +96,12 @@ def test_oracle_vs_reference_side_by_side(case, oracle_lib, ref_available):
 _SC = __import__("tests.scenarios", fromlist=["x"])
 
 
-@pytest.mark.parametrize("name", list(_SC.OPTION_BRANCHES) + list(_SC.QUICK_SOLVE_BRANCHES) + list(_SC.IMPLICIT_BRANCHES))
+@pytest.mark.parametrize("name", _SC.all_scenarios()[0])
 def test_oracle_vs_reference_option_branches(name, oracle_lib, ref_available):
     """Every run-time option branch of the path (tests/scenarios.py: EXP_TRANS, NOFLUX, node counts, GRND_FLUX_TYPE,
-    AERO_RESIST_CANSNOW, SNTHERM / SUN1999 / VIC_412, TFALLBACK off, forced solver failures, GLACIER_DYNAMICS): the oracle
-    against the real reference side by side, bit for bit -- including which cells return ERROR and the fallback flags and
-    counters."""
+    AERO_RESIST_CANSNOW, SNTHERM / SUN1999 / VIC_412, TFALLBACK off, forced solver failures, GLACIER_DYNAMICS, QUICK_SOLVE,
+    IMPLICIT) and 14 seeded random combinations of them: the oracle against the real reference side by side, bit for bit --
+    including which cells return ERROR and the fallback flags and counters."""
     if not ref_available:
         pytest.skip("reference build (oracle/_ref) not available")
     from tests import scenarios
@@ -113,6 +113,8 @@ def test_oracle_vs_reference_option_branches(name, oracle_lib, ref_available):
         isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
         sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
         ref.set_state(sd0, si0)
+    # the node geometry as initialize_model_state recomputed it (EXP_TRANS: exp() of the generator vs the reference's libm)
+    d.cell_params[...] = ref.get_cell_params()
     orc = oracle_lib.OracleModel(d)
     orc.set_state(sd0, si0)
     orc.set_fluxes(ref.get_fluxes())     # what initialize_model_state leaves in the HRUs besides the state (frost fronts ...)
