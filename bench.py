@@ -88,12 +88,12 @@ def cpu_baseline(cfg, target_seconds=15.0):
     variant = "plain" if not opt.FROZEN_SOIL else ("compat" if opt.frozen_compat else "fixed")
     kind = "reference" if pyref.have_ref(variant) else "port"
 
-    def run(ncell_s, nsteps):
+    def run(ncell_s, nsteps, threads=0):
         d = domain.make_domain(ncell_s, copy.copy(opt), ntile=cfg["ntile"], glacier_top_band=cfg.get("glacier", False))
         f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=cfg["start_doy"])
         sd0, si0 = init_state.initial_state(d, f[0])
         m = pyref.RefModel(d, variant) if kind == "reference" else pyref.OracleModel(d)
-        nthreads = int(getattr(m.lib, m.prefix + "max_threads")())
+        nthreads = threads or int(getattr(m.lib, m.prefix + "max_threads")())
         m.set_state(sd0, si0)
         secs = m.run(f, sf, dmy, nthreads)
         m.close()
@@ -108,9 +108,14 @@ def cpu_baseline(cfg, target_seconds=15.0):
     nsteps = int(min(2400, max(12, target_seconds * rate / ncell_s)))      # small domains: more steps instead of more cells
     secs, nthreads = run(ncell_s, nsteps)
     rate = ncell_s * nsteps / secs
+    # the same code on ONE thread (the all-cores figure above is far from cores x this: the reference allocates per call,
+    # full_energy.c:173, prepare_full_energy.c:45, and the sample is cold)
+    n1 = max(16, min(256, int(3.0 * rate / max(1, nthreads) / 12)))
+    secs1, _ = run(n1, 12, threads=1)
     return {"value": rate, "unit": "cell-timesteps/s", "cores": nthreads, "kind": kind,
             "sample": "%d cells x %d steps of the same workload (%.1f s, OpenMP over cells, %s)" % (
-                ncell_s, nsteps, secs, "reference build oracle/_ref/libvicref_%s.so" % variant if kind == "reference" else "oracle/libvicoracle.so")}
+                ncell_s, nsteps, secs, "reference build oracle/_ref/libvicref_%s.so" % variant if kind == "reference" else "oracle/libvicoracle.so"),
+            "one_thread_value": n1 * 12 / secs1, "one_thread_sample": "%d cells x 12 steps, 1 thread (%.1f s)" % (n1, secs1)}
 
 
 def csrc_digest():
@@ -182,6 +187,7 @@ def main():
                     help="frozen-node root finder (vicgpu_options.NODE_SOLVER): converged Newton (default) or the reference's Brent iteration replayed")
     ap.add_argument("--no-strict-leg", action="store_true", help="skip the second timing with the other node solver (N = 1)")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the PCIe-inclusive timing (forcing streamed in chunks, N = 1)")
+    ap.add_argument("--no-compat-leg", action="store_true", help="skip the 4-step timing of frozen_compat = 1 (the reference's FROZEN_SOIL as shipped, N = 1)")
     ap.add_argument("--ncell", type=int, default=0, help="override cells per GPU (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -301,6 +307,22 @@ def main():
         torch.cuda.synchronize()
         other_ms = (time.perf_counter() - ts) / K * 1e3
         m2.close()
+    # FROZEN_SOIL exactly as the reference ships it (frozen_soil.c:218-221, SURVEY.md Finding 1.2 / 8(d) "both reported"): a few
+    # steps of the same workload with frozen_compat = 1
+    compat_ms = None
+    if world == 1 and opt.FROZEN_SOIL and not opt.frozen_compat and not args.no_compat_leg:
+        import copy
+        d4 = copy.copy(d)
+        d4.opt = copy.copy(opt)
+        d4.opt.frozen_compat = 1
+        m4 = make_model(d4)
+        m4.dist_prec(0, 1, sync=True)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        m4.dist_prec(1, 4, sync=True)
+        torch.cuda.synchronize()
+        compat_ms = (time.perf_counter() - ts) / 4 * 1e3
+        m4.close()
     # PCIe-inclusive rate (N = 1): the same K steps with the forcing arriving as hourly RAW values in chunks of 6 steps from
     # pinned host memory, each chunk uploading (and derived on the device) while the previous one runs
     stream_ms = None
@@ -352,6 +374,7 @@ def main():
                        "node_solver": args.node_solver,
                        ("strict_replay_ms_per_step" if args.node_solver == "newton" else "newton_ms_per_step"): other_ms,
                        "streamed_raw_forcing_ms_per_step": stream_ms,
+                       "compat_ms_per_step": compat_ms,
                        "put_data": "on device every step (vic_put_sum / _finish / _aggregate), out_step_ratio %d" % OUT_STEP_RATIO,
                        "output_table": "%s as float32 [%d][%d]" % (",".join(OUT_VARS), full.shape[0], full.shape[1]),
                        "cells_with_error_flags": nerr, "output_gather_ms": gather_ms,

@@ -27,6 +27,10 @@ SCENARIOS = {
     "frozen_fixed": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=0), "fixed", 4, 3, False, 72, 20, 6),
     "frozen_compat": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, frozen_compat=1), "compat", 4, 3, False, 48, 20, 6),
     "frozen_fixed_glacier": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=8, Nband=2, frozen_compat=0), "fixed", 4, 2, True, 72, 110, 6),
+    # the bench workloads' shape (bench.config cfg3 / cfg4: 5 bands x 5 tiles, 10 nodes, "fixed", start_doy 60), without and
+    # with the glacier slot in the top band
+    "frozen_cfg3_shape": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5, frozen_compat=0), "fixed", 4, 5, False, 48, 60, 6),
+    "frozen_cfg4_shape_glacier": (dict(FULL_ENERGY=1, FROZEN_SOIL=1, Nnode=10, Nband=5, frozen_compat=0), "fixed", 4, 5, True, 48, 60, 6),
 }
 
 
@@ -69,9 +73,13 @@ def make_gmb():
 
 
 def main():
-    make_pure()
-    make_gmb()
+    only = sys.argv[1:]                   # optional: the trajectory fixtures to (re)generate, by name
+    if not only:
+        make_pure()
+        make_gmb()
     for name, (kw, variant, ncell, ntile, glacier, nsteps, doy, stride) in SCENARIOS.items():
+        if only and name not in only:
+            continue
         opt = abi.default_options(**kw)
         d = domain.make_domain(ncell, opt, ntile=ntile, glacier_top_band=glacier)
         f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)

@@ -413,6 +413,54 @@ def test_bench_workload_against_oracle(name, solver, oracle_lib):
     assert w < FREE_TOL, m
 
 
+@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
+def test_bench_workload_headline_outputs(name, oracle_lib):
+    """The solver bench.py times (NODE_SOLVER = NEWTON) on the workload bench.py times, against the UNMODIFIED oracle (the
+    reference's Brent iterate at every node, bit-exact against the reference build: tests/test_oracle.py) -- three days of
+    free running, the outputs north_star names at its 1e-5: per-HRU soil moisture, SWE, glacier storage / cumulative mass
+    balance at the end, and per-cell accumulated runoff, baseflow, evaporation and glacier mass balance."""
+    from vic_amd.api import Model
+    nsteps = 72
+    d, f, sf, dmy, sd0, si0 = _cfg3(64, nsteps, name)
+    d.opt.NODE_SOLVER = SOLVERS["newton"]
+    orc = oracle_lib.OracleModel(d)                       # no converged_nodes: the reference's own iterates
+    orc.set_state(sd0, si0)
+    gpu = Model(d)
+    gpu.set_state(sd0, si0)
+    gpu.push_forcing(f, sf, dmy)
+    gpu.dist_prec(0, nsteps)
+    acc = gpu.get_accum()
+    cv = d.hru_dparams[C["HPD_CV"]]
+    cell = d.hru_iparams[C["HPI_CELL"]]
+    isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+    ro = np.zeros(d.ncell); bf = np.zeros(d.ncell); ev = np.zeros(d.ncell); gmb = np.zeros(d.ncell)
+    for s in range(nsteps):
+        fo, co, eo = orc.step(f[s], sf[s], dmy[s])
+        assert eo.sum() == 0
+        np.add.at(ro, cell, fo[C["FX_RUNOFF"]] * cv)
+        np.add.at(bf, cell, fo[C["FX_BASEFLOW"]] * cv)
+        e = fo[C["FX_EVAP0"]] + fo[C["FX_EVAP1"]] + fo[C["FX_EVAP2"]] + fo[C["FX_CANOPYEVAP"]] \
+            + (fo[C["FX_SNOW_VAPOR_FLUX"]] + fo[C["FX_SNOW_CANOPY_VAPOR_FLUX"]]) * 1000.
+        np.add.at(ev, cell, e * cv)
+        mb = np.where(isg & ~np.isnan(fo[C["FX_GLAC_MASS_BALANCE"]]), fo[C["FX_GLAC_MASS_BALANCE"]], 0.0)
+        np.add.at(gmb, cell, mb * cv)
+    so, io = orc.get_state()
+    sg, ig = gpu.get_state()
+    assert gpu.get_cell_errors().sum() == 0
+    assert np.array_equal(io, ig), "integer state (flags, front counts, fallback counters) differs"
+    w, m = worst(so[HEADLINE_STATE_ROWS], sg[HEADLINE_STATE_ROWS], "SD_", floor=1e-4)
+    assert w < FREE_TOL, m
+    checks = {"runoff": (ro, acc[C["CA_RUNOFF"]], 1e-3), "baseflow": (bf, acc[C["CA_BASEFLOW"]], 1e-3), "evap": (ev, acc[C["CA_EVAP"]], 1e-2)}
+    if isg.any():
+        checks["glacier_mass_balance"] = (gmb, acc[C["CA_GLAC_MASS_BALANCE"]], 1e-4)
+    worst_acc = 0.0
+    for k, (a, b, fl) in checks.items():
+        dmax = rel_diff(a, b, floor=fl).max()
+        worst_acc = max(worst_acc, dmax)
+        assert dmax < FREE_TOL, (k, dmax)
+    print(name, "newton vs unmodified oracle, %d free steps: headline state %.2e, accumulated outputs %.2e" % (nsteps, w, worst_acc))
+
+
 def test_bench_workload_full_size_properties():
     """BASELINE size (100k cells x 25 HRUs = 2.5 M HRUs), size-independent properties of the GPU path:
     water balance closes per cell, no cell raises an error flag, and a second run from the same state is bit-identical
