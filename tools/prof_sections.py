@@ -14,14 +14,16 @@ CYC = {0: "stage / monolithic kernel total", 1: "load + prepare + aero", 2: "sol
        5: "compute_pot_evap", 6: "runoff", 7: "zwt + distribute_node_moisture", 8: "store", 9: "  snow_intercept (in 2)",
        10: "  snow_melt (in 2)", 11: "context get", 12: "sf_sub_post", 13: "sf_sub_pre (incl. solve_snow)", 14: "item block + context put",
        15: "sf_end (incl. runoff, zwt)",
-       20: "profile kernel: gate (write-back + fetch)", 21: "profile kernel: node entry / closed form", 22: "profile kernel: frozen-node residual",
-       23: "profile kernel: Brent step", 24: "profile kernel: node finish + loop"}
+       20: "profile kernel: gate (take items, load blocks)", 21: "profile kernel: sweeps (all node visits)", 22: "  Newton predictor loops (in 21)",
+       23: "  Newton fp64 loops (in 21)", 25: "  cold-nose Brent loops (in 21)", 24: "profile kernel: finish + write record"}
 CNT = {0: "waves (stage launches)", 1: "lanes", 2: "sub-steps (wave)",
        7: "SurfEB evals (wave)", 8: "SurfEB evals (lane)", 9: "SnowPackEB evals (wave)", 10: "SnowPackEB evals (lane)",
        11: "CanopyEB evals (wave)", 12: "CanopyEB evals (lane)",
        16: "lock-step: sweeps (wave)", 17: "lock-step: sweeps (lane)", 18: "lock-step: node visits (wave)",
-       19: "lock-step: frozen-node visits (lane)", 22: "lock-step: node visits with a Brent (wave)",
-       20: "lock-step: Brent iterations (wave)", 21: "lock-step: Brent iterations (lane)"}
+       19: "lock-step: frozen-node visits (lane)", 22: "node visits with a Newton solve (wave)",
+       20: "Newton fp64 iterations (wave)", 21: "Newton fp64 iterations (lane)",
+       23: "Newton predictor iterations (wave)", 24: "Newton predictor iterations (lane)",
+       25: "node-1 visits with a cold-nose Brent (wave)", 26: "cold-nose Brent solves (lane)", 27: "cold-nose Brent evaluations (lane)"}
 
 
 def main():
@@ -61,7 +63,11 @@ def main():
     print("kernel %.3f ms/launch over %d launches (instrumented build)" % (ms, nl))
     tot = cyc[0]
     for k, name in CYC.items():
-        print("  %-36s %14.0f cyc/wave  %5.1f %%" % (name, cyc[k] / max(cnt[0], 1), 100 * cyc[k] / tot))
+        if k >= 20:      # the profile kernel's sections: share of that kernel's own section total
+            ptot = cyc[20] + cyc[21] + cyc[24]
+            print("  %-50s %14.3e cyc  %5.1f %% of the profile kernel's sections" % (name, cyc[k], 100 * cyc[k] / max(ptot, 1)))
+        else:
+            print("  %-36s %14.0f cyc/wave  %5.1f %%" % (name, cyc[k] / max(cnt[0], 1), 100 * cyc[k] / tot))
     for k, name in CNT.items():
         print("  %-36s %14.0f" % (name, cnt[k]))
     if not args.prebuilt:

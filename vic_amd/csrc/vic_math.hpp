@@ -488,6 +488,26 @@ VIC_DEV double pow_pos(double x, double y) {
 // Brent loop's code.
 VIC_DEV double pow_pos_finite(double x, double y) { return exp(y * ln_pos(x)); }
 
+// Approximations for the predictor phase of the frozen-node Newton iteration (vic_profile.hpp): the hardware's single-
+// precision log2 / exp2 (v_log_f32, v_exp_f32; a handful of instructions against ~90 for exp(y ln x) in double) and a
+// reciprocal with one Newton-Raphson refinement instead of the IEEE division sequence.  Nothing computed with them
+// reaches a result: they only choose the point at which the double-precision iteration starts and scale its steps.
+VIC_DEV double pow_pos_approx(double x, float y) {
+#ifdef VIC_HOSTEMU
+  return (double)exp2f(y * log2f((float)x));
+#else
+  return (double)__builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf((float)x));
+#endif
+}
+VIC_DEV double rcp_refined(double d) {
+#ifdef VIC_HOSTEMU
+  return 1.0 / d;
+#else
+  const double r = __builtin_amdgcn_rcp(d);
+  return fma(fma(-d, r, 1.0), r, r);
+#endif
+}
+
 VIC_DEV double maximum_unfrozen_water(double T, double max_moist, double bubble, double expt) {
   double u;
   if (T <= 0) {

@@ -72,6 +72,18 @@ constexpr int LOCKSTEP_GATE = LOCKSTEP_GATE_LANES;   // idle lanes that must be 
 
 constexpr double NODE_ROOT_RANGE = SOIL_DT + Brent::MAXTRIES * Brent::TSTEP;   // the reference finds roots within T0 +- this
 constexpr double NODE_NEWTON_TOL = 1.e-8;                                        // last Newton step, K
+#ifndef VIC_NEWTON_PREDICTOR
+#define VIC_NEWTON_PREDICTOR 1
+#endif
+#ifndef VIC_PREDICT_TOL2
+#define VIC_PREDICT_TOL2 1.e-7
+#endif
+#ifndef VIC_NEWTON_ACCEPT
+#define VIC_NEWTON_ACCEPT 2.e-11
+#endif
+constexpr double NODE_PREDICT_TOL2 = VIC_PREDICT_TOL2;    // the predictor stops when step^2 <= this * |T| (its error is then < 1e-6 K)
+constexpr int NODE_PREDICT_MAXIT = 12;
+constexpr double NODE_NEWTON_ACCEPT = VIC_NEWTON_ACCEPT;  // (1 + |Y|) s^2 / |T| below this: the error left after the step is below 1e-11 K
 constexpr int NODE_NEWTON_MAXIT = 200;
 
 // The per-node constants of one record (PR_AT0 .. PR_EMM), see vic_surface.hpp
@@ -107,7 +119,11 @@ VIC_DEV double node_visit(bool sweeping, bool frozen_on, bool EXP_TRANS, const N
   // `steep`: visits that run the reference's Brent iteration -- all frozen visits when NEWTON is off, otherwise only the
   // discontinuous cold-nose case at node 1
   bool steep = false;
+#ifdef VIC_ABL_NONOSE          // ablation builds (tools/exp): wrong results, they only attribute time
+  const bool nose = false;
+#else
   const bool nose = NODE1 && fabs(Tdn - Tup) > 5.;
+#endif
   if (!NEWTON) steep = fz;
   else if (NODE1) steep = fz && nose;
   double x = N / K.S;                       // unfrozen node, or root in T >= 0 where ice = 0
@@ -116,11 +132,52 @@ VIC_DEV double node_visit(bool sweeping, bool frozen_on, bool EXP_TRANS, const N
 
   // ---- safeguarded Newton on f(T) = N - S T + E ice(T) in T < 0 (f(0) = N < 0 there: 0 is an upper bound of the root)
   bool act = NEWTON && fz && !steep && N < 0;
+#ifdef VIC_ABL_NONEWTON
+  act = false;
+#endif
   if (NEWTON && __any(act)) {
     PROF_WAVE(22);
-    double lo = -1.e300, hi = 0.0;
     x = act ? oldT : x;
+#if VIC_NEWTON_PREDICTOR
+    // Predictor: the same Newton iteration with the freezing curve through the hardware's single-precision log2 / exp2
+    // (relative error ~3e-7, ~35 instructions per iteration instead of ~130) until the step is small enough for the
+    // double-precision iteration below to finish in one evaluation.  It only moves the starting point: its bracket is its
+    // own (a sign of f within the approximation's noise must not narrow the bracket of the real iteration), and it gives
+    // up after NODE_PREDICT_MAXIT iterations wherever it stands.
+    {
+      const float Yf = (float)K.Y;
+      double plo = -1.e300, phi = 0.0;
+      bool pre = act;
+      int pit = 0;
+      PROF_T0(t_pre);
+      while (__any(pre)) {
+        PROF_WAVE(23); PROF_VOTE(24, pre);
+        if (pre) {
+          double Eu = K.G * pow_pos_approx(-x, Yf);
+          bool curved = true;
+          if (Eu > K.EMM) { Eu = K.EMM; curved = false; }
+          double Ei = K.EM - Eu;
+          if (Ei < 0.) { Ei = 0.; curved = false; }
+          if (Ei > K.EMM) { Ei = K.EMM; curved = false; }
+          const double f = N - K.S * x + Ei;
+          if (f > 0) plo = x; else phi = x;
+          const double den = K.S * x + (curved ? K.Y * Eu : 0.0);
+          const double step = f * x * rcp_refined(den);
+          double xn = x + step;
+          pit++;
+          // as below; the iterate stays negative and finite whatever the approximation does (phi <= 0, both ends finite or the
+          // doubling step)
+          if (!(xn > plo && xn < phi)) xn = (plo > -1.e299) ? 0.5 * (plo + phi) : x + x - 1.0;
+          if (step * step <= NODE_PREDICT_TOL2 * fabs(x) || pit >= NODE_PREDICT_MAXIT) pre = false;
+          x = xn;
+        }
+      }
+      PROF_ADD(22, t_pre);
+    }
+#endif
+    double lo = -1.e300, hi = 0.0;
     int it = 0;
+    PROF_T0(t_nw);
     while (__any(act)) {
       PROF_WAVE(20); PROF_VOTE(21, act);
       if (act) {
@@ -130,10 +187,23 @@ VIC_DEV double node_visit(bool sweeping, bool frozen_on, bool EXP_TRANS, const N
         const double f = N - K.S * x + Ei;
         if (f > 0) lo = x; else hi = x;
         const double den = K.S * x + (curved ? K.Y * Eu : 0.0);          // = x f'(x), negative
+#if VIC_NEWTON_PREDICTOR
+        const double step = f * x * rcp_refined(den);                     // a step's last digits do not matter (see below)
+#else
         const double step = f * x / den;
+#endif
         double xn = x + step;
         it++;
         if (fabs(step) <= NODE_NEWTON_TOL) act = false;                      // converged: the step is taken as it is
+#if VIC_NEWTON_PREDICTOR
+        // On the smooth branch of the curve the error left after a Newton step s is |f''/(2 f')| s^2 <= (1 + |Y|) s^2 / (2 |x|)
+        // (f' = -S - Y Eu / x, f'' = -Y (Y - 1) Eu / x^2, |x| the smaller end of the step: |s| <= 0.05 |x| keeps it within 5 %,
+        // the bound below has that margin).  When that bound is below the tolerance and the step stays
+        // clear of the kink where the ice content reaches zero (Eu = E moist; Eu is convex in T, so twice its linear change is
+        // an upper bound for small steps), the step is taken without another evaluation to confirm it.
+        else if (curved && fabs(step) <= 0.05 * fabs(x) && (1. + fabs(K.Y)) * step * step <= NODE_NEWTON_ACCEPT * fabs(x)
+                 && Eu * (1. + 2.2 * fabs(K.Y * step) * rcp_refined(fabs(x))) < K.EM) act = false;
+#endif
         else {
           // a step that leaves the bracket (a kink of the curve between x and the root) is replaced by a bisection; a step
           // down can only leave it once a lower bound is known
@@ -143,10 +213,13 @@ VIC_DEV double node_visit(bool sweeping, bool frozen_on, bool EXP_TRANS, const N
         x = xn;
       }
     }
+    PROF_ADD(23, t_nw);
   }
   // ---- the reference's Brent iteration (root_brent.c:97-337) on the reference's residual
   if (NODE1 || !NEWTON) {
     if (__any(steep)) {
+      PROF_WAVE(25); PROF_VOTE(26, steep);
+      PROF_T0(t_br);
       BrentLean br;
       br.phase = BrentLean::DONE;
       if (steep) br.start(T0j - SOIL_DT, T0j + SOIL_DT);
@@ -160,9 +233,11 @@ VIC_DEV double node_visit(bool sweeping, bool frozen_on, bool EXP_TRANS, const N
           const double ft2 = !EXP_TRANS ? K.C * (Tdn - T) - K.D * (T - Tup) : K.C * (Tdn - 2. * T + Tup) - K.D * (Tdn - Tup);
           if (NODE1 && nose && (T < Tdn && T < Tup) && (ft1 < 0 && ft2 > 0) && fabs(ft1) > fabs(ft2)) v -= ft1;
           br.advance(v);
+          PROF_LANE(27);
         }
       }
       if (steep) { x = br.b; if (br.phase == BrentLean::FAILED) failed = true; }
+      PROF_ADD(25, t_br);
     }
   }
   // the reference searches T0 +- 0.25 K, widened by 10 K up to five times (root_brent.c:183-248)
@@ -260,6 +335,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
   while (true) {
     const unsigned long long idle = __ballot(!have);
     if (more && (__popcll(idle) >= LOCKSTEP_GATE || idle == ~0ull)) {
+      PROF_T0(t_gate);
       const int nidle = __popcll(idle), leader = __ffsll((long long)idle) - 1;
       int base = 0;
       if (lane == leader) base = atomicAdd(a.next, nidle);
@@ -285,8 +361,10 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
         converged = (jlast <= 1);
         sweeping = !converged;
       }
+      PROF_ADD(20, t_gate);
     }
     if (!__any(have)) break;
+    PROF_T0(t_sweep);
     {
       double maxdiff = threshold;
       PROF_WAVE(16); PROF_VOTE(17, sweeping);
@@ -338,6 +416,8 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
         else it++;
       }
     }
+    PROF_ADD(21, t_sweep);
+    PROF_T0(t_fin);
     if (have && !sweeping) {                        // this lane's item is through: finish it and free the lane
       double T0v[NN];
       int cadd[NN];
@@ -358,6 +438,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
       a.pout[(size_t)hru * pout_hru_stride(Nn) + pout_key(Nn, ps)] = T0(0);
       have = false;
     }
+    PROF_ADD(24, t_fin);
   }
 #undef T0
 #undef KL

@@ -174,40 +174,54 @@ struct HruWork {
 };
 
 // What of HruWork has to survive from the set-up of a sub-step (before the ground-surface root finder) to its
-// bookkeeping (after it).  Everything else is either rewritten afterwards (node temperatures come back from the profile
-// solve, node moisture / ice / conductivity from distribute_node_moisture_properties, the per-step outputs from sf_end)
-// or is unchanged state that can be re-read from the state table.
-template <int NN>
+// bookkeeping (after it): what the set-up changed and the bookkeeping reads.  Everything else is either assigned by the
+// bookkeeping before it reads it (surf_post assigns the whole soil-side energy balance, layer temperatures and ice, node
+// temperatures come back from the profile solve, node moisture / ice / conductivity from distribute_node_moisture_properties,
+// the per-step outputs from sf_end) or is state the step has not touched yet and is read from the state table again
+// (load_untouched_state): layer moisture and ice, Wdew, last step's advected_sensible, the fallback counters.
 struct WCarry {
-  double moist[3], ice[3], layer_T[3];
   Snow snow;
-  VegVar vv;
   SnowEnergy se;
-  SoilEnergy so;
-  double Tcanopy, aero_resist_surface, aero_resist_overstory, out_prec, out_rain, out_snow;
+  double so_advection, aero_resist_surface, aero_resist_overstory, out_prec, out_rain, out_snow;
+};
+// ... and, in runs with more than one snow sub-step per step, what the sub-steps before this one have changed (layer ice and
+// temperature, the fallback counters) and the step's top-layer thermal properties, which the next sub-step's set-up reads
+template <int NN>
+struct WCarryMulti {
+  double ice[3], layer_T[3], kappa[2], Cs[2];
   int fbcount[NN + (NN & 1)];
+  int Tsurf_fbcount, pad_;
 };
 
 template <int NN>
-VIC_DEV void carry_out(const HruWork<NN>& w, WCarry<NN>& k) {
-#pragma unroll
-  for (int l = 0; l < 3; l++) { k.moist[l] = w.moist[l]; k.ice[l] = w.ice[l]; k.layer_T[l] = w.layer_T[l]; }
-  k.snow = w.snow; k.vv = w.vv; k.se = w.se; k.so = w.so;
-  k.Tcanopy = w.Tcanopy; k.aero_resist_surface = w.aero_resist_surface; k.aero_resist_overstory = w.aero_resist_overstory;
+VIC_DEV void carry_out(const HruWork<NN>& w, WCarry& k) {
+  k.snow = w.snow; k.se = w.se; k.so_advection = w.so.advection;
+  k.aero_resist_surface = w.aero_resist_surface; k.aero_resist_overstory = w.aero_resist_overstory;
   k.out_prec = w.out_prec; k.out_rain = w.out_rain; k.out_snow = w.out_snow;
+}
+template <int NN>
+VIC_DEV void carry_in(const WCarry& k, HruWork<NN>& w) {
+  w.snow = k.snow; w.se = k.se; w.so.advection = k.so_advection;
+  w.aero_resist_surface = k.aero_resist_surface; w.aero_resist_overstory = k.aero_resist_overstory;
+  w.out_prec = k.out_prec; w.out_rain = k.out_rain; w.out_snow = k.out_snow;
+}
+template <int NN>
+VIC_DEV void carry_out_multi(const HruWork<NN>& w, WCarryMulti<NN>& k) {
+#pragma unroll
+  for (int l = 0; l < 3; l++) { k.ice[l] = w.ice[l]; k.layer_T[l] = w.layer_T[l]; }
+  k.kappa[0] = w.so.kappa[0]; k.kappa[1] = w.so.kappa[1]; k.Cs[0] = w.so.Cs[0]; k.Cs[1] = w.so.Cs[1];
 #pragma unroll
   for (int n = 0; n < NN + (NN & 1); n++) k.fbcount[n] = (n < NN) ? w.nd.fbcount[n] : 0;
+  k.Tsurf_fbcount = w.so.Tsurf_fbcount; k.pad_ = 0;
 }
-
 template <int NN>
-VIC_DEV void carry_in(const WCarry<NN>& k, HruWork<NN>& w) {
+VIC_DEV void carry_in_multi(const WCarryMulti<NN>& k, HruWork<NN>& w) {
 #pragma unroll
-  for (int l = 0; l < 3; l++) { w.moist[l] = k.moist[l]; w.ice[l] = k.ice[l]; w.layer_T[l] = k.layer_T[l]; w.evap[l] = 0; }
-  w.snow = k.snow; w.vv = k.vv; w.se = k.se; w.so = k.so;
-  w.Tcanopy = k.Tcanopy; w.aero_resist_surface = k.aero_resist_surface; w.aero_resist_overstory = k.aero_resist_overstory;
-  w.out_prec = k.out_prec; w.out_rain = k.out_rain; w.out_snow = k.out_snow;
+  for (int l = 0; l < 3; l++) { w.ice[l] = k.ice[l]; w.layer_T[l] = k.layer_T[l]; }
+  w.so.kappa[0] = k.kappa[0]; w.so.kappa[1] = k.kappa[1]; w.so.Cs[0] = k.Cs[0]; w.so.Cs[1] = k.Cs[1];
 #pragma unroll
-  for (int n = 0; n < NN; n++) { w.nd.fbcount[n] = k.fbcount[n]; w.nd.fbflag[n] = 0; w.nd.T[n] = 0; }
+  for (int n = 0; n < NN; n++) w.nd.fbcount[n] = k.fbcount[n];
+  w.so.Tsurf_fbcount = k.Tsurf_fbcount;
 }
 
 // the sub-step sums of SubLoop (all zero until the first sub-step has been booked)
@@ -218,6 +232,26 @@ struct StepConst {
   double surf_atten, bare_albedo, ice0, moist0, root[3];
   int veg_idx, band, is_art_bare, overstory;
 };
+
+// The part of StepConst the bookkeeping after the root find reads (potential evaporation: the resistances of the six PET
+// surfaces under the sub-step's understory case and in the canopy): what a run with one sub-step per step parks instead of
+// the whole of StepConst (the rest comes from the HRU tables again)
+struct StepConstPost { double pet_under[NPET], pet_canopy[NPET], Ra_under, Ra_canopy; };
+VIC_DEV void step_const_post_out(const StepConst& C, int UnderStory, StepConstPost& q) {
+#pragma unroll
+  for (int p = 0; p < NPET; p++) { q.pet_under[p] = vsel(C.aero_pet[p], UnderStory); q.pet_canopy[p] = C.aero_pet[p].v[CANOPY]; }
+  q.Ra_under = vsel(C.Ra, UnderStory); q.Ra_canopy = C.Ra.v[CANOPY];
+}
+VIC_DEV void step_const_post_in(const StepConstPost& q, int UnderStory, StepConst& C) {
+#pragma unroll
+  for (int k = 0; k < NCASE; k++) {
+#pragma unroll
+    for (int p = 0; p < NPET; p++) C.aero_pet[p].v[k] = (k == CANOPY) ? q.pet_canopy[p] : ((k == UnderStory) ? q.pet_under[p] : 0.0);
+    C.Ra.v[k] = (k == CANOPY) ? q.Ra_canopy : ((k == UnderStory) ? q.Ra_under : 0.0);
+    C.U.v[k] = 0; C.disp.v[k] = 0; C.zref.v[k] = 0; C.z0.v[k] = 0;
+  }
+  C.surf_atten = 0; C.bare_albedo = 0; C.ice0 = 0; C.moist0 = 0;
+}
 
 // surface_fluxes (surface_fluxes.c:17-956) with CLOSE_ENERGY FALSE (both closure loops execute once), Ndist 1.
 // The reference's iter_* / step_* struct copies collapse to in-place updates of the snow side (se, snow, vv_snow) and

@@ -97,22 +97,45 @@ struct SurfEBCell {
   VegMonth vm;
   double D1, D2, bubble, dp, expt, max_moist, elevation, b_infilt, resid0, atmos_density, atmos_pressure;
 };
+// The members are grouped by who reads them (the finite-difference pipeline parks and fetches a group only for the HRUs
+// whose evaluations use it -- EBG_* class bits, decided once per root find in surf_setup's caller):
 struct SurfEBConst {
+  // [post] also read by the bookkeeping after the root find (surf_post)
   int VEG, frozen_on, INCLUDE_SNOW, SNOWING, overstory, hidx;      // hidx: the forcing sub-step of this root find
-  double delta_t, Cs1, Cs2, T1_old, T2, Ts_old, ice0, kappa1, kappa2, moist;
-  double NetShortBare, NetShortGrnd, NetShortSnow, Tair, LongBareIn, LongSnowIn, surf_atten, vp, vpd;
-  double Wdew, rainfall, Le, Advection, OldTSurf, kappa_snow, melt_energy, snow_coverage, snow_density, snow_swq, snow_water;
+  double T2;                      // bottom of the column: estimate_T1 (QUICK_FLUX); surf_post when neither FULL_ENERGY nor frozen soil
+  // [always] every evaluation
+  double delta_t, Cs1, T1_old, Ts_old, kappa1, kappa2;
+  double NetShortBare, NetShortGrnd, NetShortSnow, Tair, LongBareIn, surf_atten, vpd;
+  double Le, Advection, melt_energy, snow_coverage;
   double U_under, zref_under, disp_under, z0_under, ra_under;
-  double lmoist[3], lice[3], root[3];
+  // [frozen] frozen_on
+  double ice0, moist;
+  // [snowcov] snow_coverage > 0 and not INCLUDE_SNOW (with SurfEBMut::Tsnow_surf)
+  double kappa_snow;
+  // [incl] INCLUDE_SNOW, the thin snowpack solved together with the ground surface
+  double LongSnowIn, vp, OldTSurf, snow_density, snow_swq, snow_water;
+  // [evap] not SNOWING: arno_evap (layer 0) or canopy_evap
+  double lmoist[3], lice[3];
+  // [canopy] VEG and not SNOWING: canopy_evap / transpiration (with SurfEBMut::ra_used[1])
+  double Wdew, rainfall, root[3];
+  // [quick] QUICK_FLUX only (estimate_T1): never parked
+  double Cs2;
 };
+enum { EBG_FROZEN = 1, EBG_SNOWCOV = 2, EBG_INCL = 4, EBG_EVAP = 8, EBG_CANOPY = 16 };
 struct SurfEBMut {
-  // read by the next evaluation (read-modify-write, or kept when a branch does not assign them)
-  double Tsnow_surf;
-  double ra_used[2];
+  // [feed] carried from one evaluation to the next -- only with INCLUDE_SNOW (the mass fluxes of latent_heat_from_snow are
+  // in/out)
+  double vapor_flux, blowing_flux, surface_flux;
+  // [keep] inputs of an evaluation that it may also assign: whichever of them a root find assigns at all, every evaluation
+  // assigns before it uses it (the branch is decided by the constant flags), so an evaluation reads the values the set-up
+  // parked and only the final evaluation's values are ever written back
+  double deltaCC, NetLongSnow, fusion;          // read by every evaluation (inputs unless INCLUDE_SNOW / frozen_on)
+  double Tsnow_surf;                            // read with [snowcov]
+  double ra_used[2];                            // [1] read with [canopy]; [0] is an output
   VegVar vv;
   double layerevap[3];
-  double deltaCC, refreeze_energy, vapor_flux, blowing_flux, surface_flux, NetLongSnow, fusion;
-  // assigned by every evaluation before any use: only the final evaluation's values are ever read
+  double refreeze_energy;
+  // [out] assigned by every evaluation before any use: only the final evaluation's values are ever read
   double Tnew2;                   // Tnew_node[2] of the last evaluation
   double NetLongBare, T1, deltaH, grnd_flux, latent_heat, latent_heat_sub, sensible_heat, snow_flux, error;
 };
@@ -123,9 +146,11 @@ struct SurfEB : SurfEBCell, SurfEBConst, SurfEBMut {
     PROF_WAVE(7); PROF_LANE(8);
     const double TMean = Ts;
     const double Tmp = TMean + KELVIN;
-    if (snow_coverage > 0 && !INCLUDE_SNOW) snow_flux = (kappa_snow * (Tsnow_surf - TMean));
-    else if (INCLUDE_SNOW) { snow_flux = 0; Tsnow_surf = TMean; }
-    else snow_flux = 0;
+    // (through locals: two members assigned on alternative paths end up behind a selected address, i.e. in scratch)
+    double Tsn = Tsnow_surf, sflux = 0;
+    if (snow_coverage > 0 && !INCLUDE_SNOW) sflux = (kappa_snow * (Tsn - TMean));
+    else if (INCLUDE_SNOW) Tsn = TMean;
+    snow_flux = sflux; Tsnow_surf = Tsn;
     const double att = (snow_coverage + (1. - snow_coverage) * surf_atten);
     if (o.QUICK_FLUX) {
       T1 = estimate_T1(TMean, T1_old, T2, D1, D2, kappa1, kappa2, Cs2, dp, delta_t);
@@ -197,9 +222,9 @@ struct SurfEB : SurfEBCell, SurfEBConst, SurfEBMut {
     } else sensible_heat = 0.;
 
     double err = (NetBareRad + NetShortGrnd + NetShortSnow + 1. * (NetLongSnow)) + sensible_heat + (latent_heat + latent_heat_sub)
-                 + snow_flux * snow_coverage + melt_energy + Advection - deltaCC;
+                 + sflux * snow_coverage + melt_energy + Advection - deltaCC;
     if (INCLUDE_SNOW) {
-      if (Tsnow_surf == 0.0 && err > -(refreeze_energy)) {
+      if (Tsn == 0.0 && err > -(refreeze_energy)) {
         refreeze_energy = -err;
         err = 0.0;
       } else err += refreeze_energy;

@@ -129,38 +129,74 @@ VIC_DEV void ctx_get(const CtxRef& r, size_t word0, T& v) {
   for (int i = 0; i < NW; i++) tmp[i] = q[(size_t)i * CTX_WORD_STRIDE];
   __builtin_memcpy(&v, tmp, sizeof(T));
 }
-constexpr size_t CW_SV = sizeof(SurfSolve) / 8, CW_EBM = sizeof(SurfEBMut) / 8, CW_EBC = sizeof(SurfEBConst) / 8,
+// SurfEBConst / SurfEBMut are parked group by group (vic_surface.hpp): word ranges of the groups
+constexpr int EBC_W_POST = offsetof(SurfEBConst, delta_t) / 8, EBC_W_ALWAYS = offsetof(SurfEBConst, ice0) / 8,
+              EBC_W_FROZEN = offsetof(SurfEBConst, kappa_snow) / 8, EBC_W_SNOWCOV = offsetof(SurfEBConst, LongSnowIn) / 8,
+              EBC_W_INCL = offsetof(SurfEBConst, lmoist) / 8, EBC_W_EVAP = offsetof(SurfEBConst, Wdew) / 8,
+              EBC_W_CANOPY = offsetof(SurfEBConst, Cs2) / 8;
+constexpr int EBM_W_FEED = offsetof(SurfEBMut, deltaCC) / 8, EBM_W_IN3 = offsetof(SurfEBMut, Tsnow_surf) / 8,
+              EBM_W_TSNOW = offsetof(SurfEBMut, ra_used) / 8, EBM_W_RA1 = EBM_W_TSNOW + 1, EBM_W_KEEP = offsetof(SurfEBMut, Tnew2) / 8;
+constexpr size_t CW_SV = sizeof(SurfSolve) / 8, CW_EBM = sizeof(SurfEBMut) / 8, CW_EBC = EBC_W_CANOPY,      // Cs2 is never parked
                  CW_P = sizeof(SubStep) / 8, CW_L = sizeof(SubLoop) / 8, CW_C = sizeof(StepConst) / 8;
 constexpr size_t CO_SV = 0, CO_EBM = CO_SV + CW_SV, CO_EBC = CO_EBM + CW_EBM, CO_P = CO_EBC + CW_EBC, CO_L = CO_P + CW_P,
                  CO_C = CO_L + CW_L, CO_W = CO_C + CW_C;
-template <int NN> constexpr size_t ctx_words() { return CO_W + sizeof(WCarry<NN>) / 8; }
+constexpr size_t CW_W = sizeof(WCarry) / 8, CO_WM = CO_W + CW_W;
+template <int NN> constexpr size_t ctx_words() { return CO_WM + sizeof(WCarryMulti<NN>) / 8; }
+static_assert(sizeof(StepConstPost) <= sizeof(StepConst), "StepConstPost is parked in StepConst's words");
 // SubLoop in two parts: the head always, the sub-step sums only once a sub-step has been booked (they are zero before)
 constexpr size_t CW_L_HEAD = offsetof(SubLoop, st_AlbedoOver) / 8;
-// SurfEBMut: the fields an evaluation reads back, then the pure outputs (parked by the final evaluation only)
-constexpr size_t CW_EBM_FEED = offsetof(SurfEBMut, Tnew2) / 8;
 // SurfSolve: the Brent state and the abscissa (rewritten by every evaluation), then the rest
 constexpr size_t CW_SV_ITER = offsetof(SurfSolve, Tsurf) / 8;
 
 template <class T>
 VIC_DEV void ctx_put_words(const CtxRef& r, size_t word0, const T& v, int first, int last) {
   constexpr int NW = sizeof(T) / 8;
-  unsigned long long tmp[NW];
-  __builtin_memcpy(tmp, &v, sizeof(T));
   unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
   for (int i = 0; i < NW; i++)
-    if (i >= first && i < last) q[(size_t)i * CTX_WORD_STRIDE] = tmp[i];
+    if (i >= first && i < last) {
+      unsigned long long w;
+      __builtin_memcpy(&w, reinterpret_cast<const char*>(&v) + 8 * i, 8);
+      q[(size_t)i * CTX_WORD_STRIDE] = w;
+    }
 }
+// word by word into the object (no whole-struct copy: the conditional group loads of the evaluation kernel must not make the
+// struct an aggregate the optimiser keeps in memory)
 template <class T>
 VIC_DEV void ctx_get_words(const CtxRef& r, size_t word0, T& v, int first, int last) {
   constexpr int NW = sizeof(T) / 8;
-  unsigned long long tmp[NW];
-  __builtin_memcpy(tmp, &v, sizeof(T));
   const unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
   for (int i = 0; i < NW; i++)
-    if (i >= first && i < last) tmp[i] = q[(size_t)i * CTX_WORD_STRIDE];
-  __builtin_memcpy(&v, tmp, sizeof(T));
+    if (i >= first && i < last) {
+      const unsigned long long w = q[(size_t)i * CTX_WORD_STRIDE];
+      __builtin_memcpy(reinterpret_cast<char*>(&v) + 8 * i, &w, 8);
+    }
+}
+
+// The residual's inputs, group by group: `cls` = EBG_* bits of the HRU's root find (which groups its evaluations use)
+VIC_DEV int surf_eb_class(const SurfEBConst& c) {
+#ifdef VIC_DEBUG_ALLGROUPS
+  return VIC_DEBUG_ALLGROUPS;
+#endif
+  return (c.frozen_on ? EBG_FROZEN : 0) | ((c.snow_coverage > 0 && !c.INCLUDE_SNOW) ? EBG_SNOWCOV : 0) | (c.INCLUDE_SNOW ? EBG_INCL : 0)
+         | (!c.SNOWING ? EBG_EVAP : 0) | ((c.VEG && !c.SNOWING) ? EBG_CANOPY : 0);
+}
+VIC_DEV void ebc_put(const CtxRef& cx, const SurfEBConst& c, int cls) {
+  ctx_put_words(cx, CO_EBC, c, 0, EBC_W_ALWAYS);
+  if (cls & EBG_FROZEN) ctx_put_words(cx, CO_EBC, c, EBC_W_ALWAYS, EBC_W_FROZEN);
+  if (cls & EBG_SNOWCOV) ctx_put_words(cx, CO_EBC, c, EBC_W_FROZEN, EBC_W_SNOWCOV);
+  if (cls & EBG_INCL) ctx_put_words(cx, CO_EBC, c, EBC_W_SNOWCOV, EBC_W_INCL);
+  if (cls & EBG_EVAP) ctx_put_words(cx, CO_EBC, c, EBC_W_INCL, EBC_W_EVAP);
+  if (cls & EBG_CANOPY) ctx_put_words(cx, CO_EBC, c, EBC_W_EVAP, EBC_W_CANOPY);
+}
+VIC_DEV void ebc_get(const CtxRef& cx, SurfEBConst& c, int cls) {
+  ctx_get_words(cx, CO_EBC, c, 0, EBC_W_ALWAYS);
+  if (cls & EBG_FROZEN) ctx_get_words(cx, CO_EBC, c, EBC_W_ALWAYS, EBC_W_FROZEN);
+  if (cls & EBG_SNOWCOV) ctx_get_words(cx, CO_EBC, c, EBC_W_FROZEN, EBC_W_SNOWCOV);
+  if (cls & EBG_INCL) ctx_get_words(cx, CO_EBC, c, EBC_W_SNOWCOV, EBC_W_INCL);
+  if (cls & EBG_EVAP) ctx_get_words(cx, CO_EBC, c, EBC_W_INCL, EBC_W_EVAP);
+  if (cls & EBG_CANOPY) ctx_get_words(cx, CO_EBC, c, EBC_W_EVAP, EBC_W_CANOPY);
 }
 
 // wave-aggregated append of this lane's HRU to segment `key` of a work list (order is irrelevant: HRUs never interact).
@@ -269,12 +305,31 @@ VIC_DEV void load_node_props(const KArgs& a, int g, Nodes<NN>& nd) {
   }
 }
 
-// what load_state gives the fields that neither cross the root finder in the parked context nor are rewritten after it
+// Phase p >= 1 of the stage kernel: the part of the HRU's working set that neither crosses the root finder in the parked
+// context nor is assigned by the bookkeeping before it is read -- state the step has not touched yet, from the state table
+// (see WCarry, vic_step.hpp); what the bookkeeping assigns starts as zero.
 template <int NN>
-VIC_DEV void load_passthrough(const KArgs& a, int g, HruWork<NN>& w) {
+VIC_DEV void load_untouched_state(const KArgs& a, int g, HruWork<NN>& w) {
+  const int Nn = a.o.Nnode;
   const size_t nh = a.nhru;
   const double* __restrict__ sd = a.sd;
   const int* __restrict__ si = a.si;
+#pragma unroll
+  for (int l = 0; l < 3; l++) {
+    w.moist[l] = sd[(size_t)(SD_MOIST0 + l) * nh + g]; w.ice[l] = sd[(size_t)(SD_ICE0 + l) * nh + g];
+    w.layer_T[l] = sd[(size_t)(SD_LAYER_T0 + l) * nh + g]; w.evap[l] = 0;
+  }
+  w.vv.Wdew = sd[(size_t)SD_WDEW * nh + g]; w.vv.canopyevap = 0; w.vv.throughfall = 0;
+  SoilEnergy& so = w.so;
+  so.deltaCC = 0; so.refreeze_energy = 0; so.deltaH = 0; so.fusion = 0; so.grnd_flux = 0; so.latent = 0; so.latent_sub = 0; so.sensible = 0;
+  so.snow_flux = 0; so.error = 0; so.NetShortGrnd = 0; so.NetLongUnder = 0; so.NetShortUnder = 0; so.LongUnderOut = 0; so.AlbedoUnder = 0;
+  so.melt_energy = 0; so.Tsurf = 0; so.kappa[0] = so.kappa[1] = so.Cs[0] = so.Cs[1] = 0;
+#pragma unroll
+  for (int f = 0; f < 3; f++) { so.fdepth[f] = 0; so.tdepth[f] = 0; }
+  so.advected_sensible = sd[(size_t)SD_ADVECTED_SENSIBLE * nh + g];
+  so.Tsurf_fbflag = 0; so.Tsurf_fbcount = si[(size_t)SI_TSURF_FBCOUNT * nh + g];
+  so.frozen = 0; so.Nfrost = 0; so.Nthaw = si[(size_t)SI_NTHAW * nh + g];
+  w.Tcanopy = 0;
   w.gl.surf_temp = sd[(size_t)SD_GLAC_SURF_TEMP * nh + g]; w.gl.water_storage = sd[(size_t)SD_GLAC_WATER_STORAGE * nh + g];
   w.gl.cum_mass_balance = sd[(size_t)SD_GLAC_CUM_MASS_BALANCE * nh + g];
   w.gl.cold_content = NAN; w.gl.Qnet = NAN; w.gl.mass_balance = NAN; w.gl.ice_mass_balance = 0; w.gl.accumulation = NAN;
@@ -282,7 +337,10 @@ VIC_DEV void load_passthrough(const KArgs& a, int g, HruWork<NN>& w) {
   w.gl.surf_temp_fbcount = si[(size_t)SI_GLAC_SURF_TEMP_FBCOUNT * nh + g]; w.gl.surf_temp_fbflag = si[(size_t)SI_GLAC_SURF_TEMP_FBFLAG * nh + g];
   w.deltaCC_glac = 0; w.glacier_flux = 0; w.glacier_melt_energy = 0;
 #pragma unroll
-  for (int n = 0; n < NN; n++) { w.nd.moist[n] = 0; w.nd.ice[n] = 0; w.nd.kappa[n] = 0; w.nd.Cs[n] = 0; }
+  for (int n = 0; n < NN; n++) {
+    w.nd.T[n] = 0; w.nd.moist[n] = 0; w.nd.ice[n] = 0; w.nd.kappa[n] = 0; w.nd.Cs[n] = 0; w.nd.fbflag[n] = 0;
+    w.nd.fbcount[n] = (n < Nn) ? si[(size_t)VICGPU_SI_NODE(SIN_T_FBCOUNT, n, Nn) * nh + g] : 0;
+  }
 #pragma unroll
   for (int p = 0; p < NPET; p++) w.pot_evap[p] = 0;
 }
@@ -592,7 +650,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
   const HruId id = hru_id(a, g);
   if (id.run && id.is_glacier) return;              // vic_hru_step<NN, true> owns glacier HRUs
   if (FIRST && !id.run) { store_zero_record(a, g); a.hstate[g] = 0; return; }
-  if (!FIRST && a.hstate[g] != 2) return;
+  if (!FIRST && (a.hstate[g] & 3) != 2) return;
   CellView cv{a.cell_params, a.ncell, id.c, o.Nnode, o.Nband};
   VegLib vl{a.veglib};
   Forcing fc{a.forcing, a.snowflag, a.ncell, id.c, o.NR + 1};
@@ -614,19 +672,36 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
     SubStep P;
     SurfEB eb;
     SurfSolve sv;
-    WCarry<NN> k;
-    ctx_get(cx, CO_SV, sv);
+    ctx_get_words(cx, CO_SV, sv, (int)CW_SV_ITER, (int)CW_SV);                     // the result of the root find, not the Brent state
     ctx_get(cx, CO_EBM, static_cast<SurfEBMut&>(eb));
-    ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
+    ctx_get_words(cx, CO_EBC, static_cast<SurfEBConst&>(eb), 0, EBC_W_POST);      // the bookkeeping reads the flags and T2 only
     surf_cell_fill(eb, cv, vl, s3, fc, eb.hidx, id.veg_idx, a.dmy.month);
     ctx_get(cx, CO_P, P);
     ctx_get_words(cx, CO_L, L, 0, (int)CW_L_HEAD);
     if (MULTI && L.N_steps > 0) ctx_get_words(cx, CO_L, L, (int)CW_L_HEAD, (int)CW_L);
     else zero_substep_sums(L);
-    ctx_get(cx, CO_C, C);
-    ctx_get(cx, CO_W, k);
-    carry_in<NN>(k, w);
-    load_passthrough<NN>(a, g, w);
+    load_untouched_state<NN>(a, g, w);
+    if constexpr (MULTI) {
+      ctx_get(cx, CO_C, C);
+      WCarryMulti<NN> km;
+      ctx_get(cx, CO_WM, km);
+      carry_in_multi<NN>(km, w);
+    } else {
+      // one sub-step per step: of StepConst the bookkeeping needs the PET resistances of this sub-step's surface cases (parked),
+      // the rest is in the HRU tables
+      StepConstPost q;
+      ctx_get(cx, CO_C, q);
+      step_const_post_in(q, P.UnderStory, C);
+      C.veg_idx = id.veg_idx; C.band = id.band; C.is_art_bare = id.is_art_bare ? 1 : 0;
+      C.overstory = (vl.f(id.veg_idx, VL_OVERSTORY) != 0.0) ? 1 : 0;
+#pragma unroll
+      for (int l = 0; l < 3; l++) C.root[l] = (double)(float)a.hpd[(size_t)(HPD_ROOT0 + l) * a.nhru + g];
+    }
+    {
+      WCarry k;
+      ctx_get(cx, CO_W, k);
+      carry_in<NN>(k, w);
+    }
     PROF_ADD(11, t_stage);
     PROF_T0(t_post);
     // the soil profile of the final evaluation
@@ -656,14 +731,24 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
       PROF_ADD(13, t_pre);
       PROF_T0(t_put);
       ctx_put(cx, CO_SV, sv);
-      ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
-      ctx_put(cx, CO_EBC, static_cast<const SurfEBConst&>(eb));
+      ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, EBM_W_KEEP);   // the outputs are the final evaluation's to write
+      const int cls = surf_eb_class(eb);
+      ebc_put(cx, eb, cls);
       ctx_put(cx, CO_P, P);
       ctx_put_words(cx, CO_L, L, 0, (int)CW_L_HEAD);
       if (MULTI && L.N_steps > 0) ctx_put_words(cx, CO_L, L, (int)CW_L_HEAD, (int)CW_L);
-      if (FIRST) ctx_put(cx, CO_C, C);
+      if constexpr (MULTI) {
+        if (FIRST) ctx_put(cx, CO_C, C);
+        WCarryMulti<NN> km;
+        carry_out_multi<NN>(w, km);
+        ctx_put(cx, CO_WM, km);
+      } else {
+        StepConstPost q;
+        step_const_post_out(C, P.UnderStory, q);
+        ctx_put(cx, CO_C, q);
+      }
       {
-        WCarry<NN> k;
+        WCarry k;
         carry_out<NN>(w, k);
         ctx_put(cx, CO_W, k);
       }
@@ -711,7 +796,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
       }
       a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 0)] = NAN;      // no solve on record yet
       a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 1)] = NAN;
-      a.hstate[g] = 1;
+      a.hstate[g] = 1 | (cls << 2);
       pend = true;
       PROF_ADD(14, t_put);
     }
@@ -761,7 +846,9 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   if (gi == 0) *a.profile_next = 0;
   if (gi >= a.gcount) return;
   const int g = a.glist ? a.glist[gi] : gi;
-  if (a.hstate[g] != 1) return;
+  const int hs = a.hstate[g];
+  if ((hs & 3) != 1) return;
+  const int cls = hs >> 2;
   const size_t nh = a.nhru;
   const int c = a.hpi[(size_t)HPI_CELL * nh + g];
   CellView cv{a.cell_params, a.ncell, c, a.o.Nnode, a.o.Nband};
@@ -770,8 +857,19 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   SurfEB eb;
   const CtxRef cx = CtxRef::at(a.ctx, a.ctx_words, g);
   ctx_get(cx, CO_SV, sv);
-  ctx_get_words(cx, CO_EBM, static_cast<SurfEBMut&>(eb), 0, (int)CW_EBM_FEED);
-  ctx_get(cx, CO_EBC, static_cast<SurfEBConst&>(eb));
+  ebc_get(cx, eb, cls);
+  {
+    // of SurfEBMut an evaluation of the iteration reads what it cannot know otherwise; the final one reads every input, since
+    // what it does not assign passes through to the bookkeeping (vic_surface.hpp)
+    SurfEBMut& m = eb;
+    if (sv.stage == SurfSolve::FINAL) ctx_get_words(cx, CO_EBM, m, 0, EBM_W_KEEP);
+    else {
+      if (cls & EBG_INCL) ctx_get_words(cx, CO_EBM, m, 0, EBM_W_FEED);
+      ctx_get_words(cx, CO_EBM, m, EBM_W_FEED, EBM_W_IN3);
+      if (cls & EBG_SNOWCOV) ctx_get_words(cx, CO_EBM, m, EBM_W_IN3, EBM_W_TSNOW);
+      if (cls & EBG_CANOPY) ctx_get_words(cx, CO_EBM, m, EBM_W_RA1, EBM_W_RA1 + 1);
+    }
+  }
   {
     const VegLib vl{a.veglib};
     const Forcing fc{a.forcing, nullptr, a.ncell, c, a.o.NR + 1};
@@ -805,8 +903,8 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   // flags, stage, record bookkeeping) is written when it does
   if (sv.stage == stage_before && (sv.stage == SurfSolve::ROOT || sv.stage == SurfSolve::ROOT_QUICK)) ctx_put_words(cx, CO_SV, sv, 0, (int)CW_SV_ITER);
   else ctx_put(cx, CO_SV, sv);
-  ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, (int)CW_EBM_FEED);
-  if (sv.stage == SurfSolve::DONE) ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), (int)CW_EBM_FEED, (int)CW_EBM);
+  if (sv.stage == SurfSolve::DONE) ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
+  else if (cls & EBG_INCL) ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, EBM_W_FEED);
   if (sv.stage == SurfSolve::DONE) a.hstate[g] = 2;
   else if (need_solve) { a.ts[g] = sv.x; a.pslot[g] = slot ^ 1; }     // keep the record just used, overwrite the older one
   list_append(a.list_next, a.count_next, a.list_cap, need_solve, a.hkey[g], g);
