@@ -652,10 +652,12 @@ int vicorc_state_records(void *hv, double *rec, int write) {
 /* initialize_atmos.c: atmos[rec] from one record of hourly forcing, for the case every variable is supplied sub-daily
  * (raw [nsteps][VIC_NRAW][dt][ncell], kPa for the two pressures): kPa -> Pa (:290-295), the snow_step-hour aggregation
  * with mean / sum in sub-index NR (:886-893 and its siblings), the MIN_WIND_SPEED floor per hour (:518-536), density from
- * pressure (:980-1000), vpd = svp(T) - vp clipped at 0 with vp reset (:1175-1193), snowflag (:1275-1303).
- * NOT pinned against the reference: initialize_atmos needs read_atmos_data / the forcing-file machinery, which is not on
- * the path this repository can build (oracle/ref_build/build_ref.sh). */
-int vicorc_derive_forcing(void *hv, int nsteps, const double *raw, double min_wind, int plapse, double *forcing, unsigned char *snowflag) {
+ * pressure (:980-1000; sub-index NR from pressure[NR] and air_temp[NR], not the mean of the sub-steps' densities), vpd =
+ * svp(T) - vp clipped at 0 with vp reset (:1175-1193), snowflag (:1275-1303); MIN_WIND_SPEED is a float option
+ * (vicNl_def.h:713).  Pinned bit for bit against the reference's own initialize_atmos run on in-memory records
+ * (oracle/ref_build/vicref_shim.cpp vicref_derive_forcing, tests/test_forcing_stream.py). */
+int vicorc_derive_forcing(void *hv, int nsteps, const double *raw, double min_wind_in, int plapse, double *forcing, unsigned char *snowflag) {
+  const double min_wind = (double)(float)min_wind_in;
   vicorc_handle *h = (vicorc_handle *)hv;
   const vicgpu_options *o = &h->model.opt;
   const int NF = h->model.NF, NR = h->model.NR, ns = NR + 1, dt = o->dt, ss = o->snow_step;
@@ -698,6 +700,8 @@ int vicorc_derive_forcing(void *hv, int nsteps, const double *raw, double min_wi
       }
       if (NF > 1) {
         for (v = 0; v < VIC_NFORCE; v++) FO(v, NR) = (v == VIC_F_PREC) ? sum[v] : sum[v] / (double)(float)NF;
+        FO(VIC_F_DENSITY, NR) = plapse ? FO(VIC_F_PRESSURE, NR) / (287.0 * (ORC_KELVIN + FO(VIC_F_AIR_TEMP, NR)))
+                                       : 0.003486 * FO(VIC_F_PRESSURE, NR) / (275.0 + FO(VIC_F_AIR_TEMP, NR));
         sf[(size_t)NR * nc] = (unsigned char)any;
       }
 #undef RAW

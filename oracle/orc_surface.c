@@ -286,9 +286,32 @@ static int orc_solve_T_profile(const orc_model *m, double *T, const double *T0, 
         c.TL = T[j + 1]; c.TU = T[j - 1]; c.T0 = T0[j]; c.moist = moist[j];
         orc_node_freeze_params(m, sc, j, &c.max_moist, &c.bubble, &c.expt);
         c.ice0 = ice[j]; c.A = A[j]; c.B = B[j]; c.C = C[j]; c.D = D[j]; c.E = E[j]; c.EXP_TRANS = EXP_TRANS; c.node = j;
-        /* the cold-nose variant of the residual (node 1, |TL - TU| > 5) is discontinuous: its root depends on the
-         * iteration's path, so the test knob (orc.h) never applies to it */
-        if (j == 1 && fabs(c.TL - c.TU) > 5.) T[j] = orc_root_brent(T0[j] - (ORC_SOIL_DT), T0[j] + (ORC_SOIL_DT), orc_soil_thermal_eqn, &c);
+        /* The cold-nose variant of the residual (node 1, |TL - TU| > 5; soil_thermal_eqn.c:57-72, 84-93) drops the flux term
+         * ft1 = B (TL - TU) on an interval Tb < T < Thi below both neighbours when ft1 < 0: the residual then is discontinuous
+         * and may change sign more than once, in which case the root depends on the iteration's path and the test knob
+         * (orc.h) does not apply.  It does apply when the sign change is unique: the tightened iteration on this same
+         * residual then converges to it, and a sign change at or above Thi can only be the root of the smooth branch, above
+         * which the residual is the smooth branch and below which it is positive throughout. */
+        if (j == 1 && fabs(c.TL - c.TU) > 5.) {
+          const double ref_T = orc_root_brent(T0[j] - (ORC_SOIL_DT), T0[j] + (ORC_SOIL_DT), orc_soil_thermal_eqn, &c);
+          T[j] = ref_T;
+          if (m->node_ttol < 1e-7) {
+            const double Tt = orc_root_brent_tol(T0[j] - (ORC_SOIL_DT), T0[j] + (ORC_SOIL_DT), orc_soil_thermal_eqn, &c, m->node_macheps, m->node_ttol);
+            const double ft1 = c.B * (c.TL - c.TU);
+            int several = 0;
+            if (ft1 < 0) {
+              double Thi = (c.TL < c.TU) ? c.TL : c.TU, Tb;
+              if (!EXP_TRANS) Tb = (c.C * c.TL + c.D * c.TU + ft1) / (c.C + c.D);
+              else {
+                const double num = c.C * (c.TL + c.TU) - c.D * (c.TL - c.TU), Ta = num / (2. * c.C);
+                if (Ta < Thi) Thi = Ta;
+                Tb = (num + ft1) / (2. * c.C);
+              }
+              several = (Tb < Thi) && (orc_is_error(Tt) || Tt < Thi + 1.e-6);
+            }
+            if (!several && !orc_is_error(Tt)) T[j] = Tt;
+          }
+        }
         else T[j] = orc_root_brent_tol(T0[j] - (ORC_SOIL_DT), T0[j] + (ORC_SOIL_DT), orc_soil_thermal_eqn, &c, m->node_macheps, m->node_ttol);
         if (orc_is_error(T[j])) {
           if (m->opt.TFALLBACK) { T[j] = T0[j]; Tfbflag[j] = 1; Tfbcount[j]++; }

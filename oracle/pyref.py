@@ -176,6 +176,21 @@ class RefModel(_Model):
         self.lib.vicref_get_cell_params(self.h, _d(out))
         return out
 
+    def derive_forcing(self, file, force_dt, min_wind=0.0, plapse=1):
+        """The reference's own initialize_atmos (initialize_atmos.c:7-1349) on forcing records held in memory
+        (oracle/ref_build/vicref_shim.cpp: the harness is the file reader, everything else is the reference).
+        file [VIC_NRAW][nsteps * dt / force_dt][ncell] in file units (kPa); returns (forcing, snowflag) as vicgpu_push_forcing takes them."""
+        file = np.ascontiguousarray(file, dtype=np.float64)
+        o = self.dom.opt
+        nsteps = file.shape[1] * force_dt // o.dt
+        nsub = o.NR + 1
+        f = np.zeros((nsteps, C["VIC_NFORCE"], nsub, self.dom.ncell)); sf = np.zeros((nsteps, nsub, self.dom.ncell), dtype=np.uint8)
+        fn = self.lib.vicref_derive_forcing; fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_double, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_ubyte)]
+        rc = fn(self.h, nsteps, int(force_dt), _d(file), float(min_wind), int(plapse), _d(f), sf.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+        assert rc == 0, rc
+        return f, sf
+
     def output_list(self):
         """The reference's own output variable list: {name: (index, nelem, aggtype)} (create_output_list)."""
         self.lib.vicref_out_nvar.restype = ctypes.c_int

@@ -84,6 +84,23 @@ public:
 };
 
 
+/* ---- initialize_atmos (initialize_atmos.c:7-1349) driven from memory.  read_forcing_data.c calls read_atmos_data for each
+ * forcing file; the reference's read_atmos_data.c parses a NetCDF / ASCII / binary file and is not part of this build (it
+ * needs the netCDF C library).  The harness supplies the file-reading end itself: the "file" is a table the test filled,
+ * [type][record at the forcing time step], copied into forcing_data[] exactly as read_atmos_data leaves the values of a
+ * file (file units: kPa for PRESSURE and VP; initialize_atmos converts).  Everything downstream -- local-time arrays, MTCLIM,
+ * sub-step aggregation, vpd, density, snowflag -- is the reference's own code. */
+struct VicrefForcingSource { const double *data[N_FORCING_TYPES]; int nrec; };
+static thread_local const VicrefForcingSource *vicref_forcing_source = NULL;
+
+void read_atmos_data(FILE *, int, int file_num, int, double **forcing_data, soil_con_struct *, const ProgramState *state) {
+  const VicrefForcingSource *src = vicref_forcing_source;
+  if (!src || file_num != 0) throw VICException("vicref: read_atmos_data without an in-memory forcing source");
+  for (int t = 0; t < N_FORCING_TYPES; t++)
+    if (state->param_set.TYPE[t].SUPPLIED && src->data[t])
+      for (int k = 0; k < src->nrec; k++) forcing_data[t][k] = src->data[t][k];
+}
+
 extern "C" {
 
 void *vicref_create(const vicgpu_options *opt) {
@@ -671,6 +688,83 @@ int vicref_pure(void *hv, int fn, int n, const double *in, double *out) {
       default: return -1;
     }
     out[i] = r;
+  }
+  return 0;
+}
+
+/* atmos[rec] of every cell from sub-daily forcing supplied at `force_dt`-hour steps (force_dt = 1, or = snow_step): the
+ * reference's initialize_atmos on in-memory records.  file[v][k][cell], v = VIC_RAW_* (file units), k < nsteps * dt / force_dt.
+ * Out: forcing [nsteps][VIC_NFORCE][NR+1][ncell] and snowflag [nsteps][NR+1][ncell] in the layout of vicgpu_push_forcing.
+ * nsteps * dt must be whole days starting at hour 0 (the cell's time zone is its own longitude: no local-time shift). */
+int vicref_derive_forcing(void *hv, int nsteps, int force_dt, const double *file, double min_wind, int plapse, double *forcing,
+                          unsigned char *snowflag) {
+  vicref_handle *h = (vicref_handle *)hv;
+  const int dt = h->opt.dt, NR = h->NR, NF = h->NF, nc = h->ncell;
+  if (nsteps <= 0 || (nsteps * dt) % 24 != 0 || (force_dt != 1 && force_dt != h->opt.snow_step)) return -1;
+  if (force_dt == 1 && h->opt.snow_step != 1) return -1;        /* forcing_data[] holds nrecs * NF values (read_forcing_data.c:31) */
+  const int nfile = nsteps * dt / force_dt;
+  ProgramState st = h->state;
+  st.global_param.nrecs = nsteps;
+  st.global_param.starthour = 0; st.global_param.startyear = 2001; st.global_param.startmonth = 1; st.global_param.startday = 1;
+  st.global_param.forceskip[0] = 0; st.global_param.forceskip[1] = 0;
+  st.options.MIN_WIND_SPEED = min_wind;
+  st.options.PLAPSE = plapse ? TRUE : FALSE;
+  st.options.OUTPUT_FORCE = FALSE;
+  st.options.COMPUTE_TREELINE = FALSE;
+  st.options.ALMA_INPUT = FALSE;
+  for (int t = 0; t < N_FORCING_TYPES; t++) st.param_set.TYPE[t].SUPPLIED = 0;
+  const int types[VIC_NRAW] = {AIR_TEMP, PREC, PRESSURE, VP, SHORTWAVE, LONGWAVE, WIND};
+  const int raws[VIC_NRAW] = {VIC_RAW_AIR_TEMP, VIC_RAW_PREC, VIC_RAW_PRESSURE_KPA, VIC_RAW_VP_KPA, VIC_RAW_SHORTWAVE, VIC_RAW_LONGWAVE, VIC_RAW_WIND};
+  for (int i = 0; i < VIC_NRAW; i++) st.param_set.TYPE[types[i]].SUPPLIED = 1;
+  st.param_set.FORCE_DT[0] = force_dt; st.param_set.FORCE_DT[1] = INVALID_INT;
+  std::vector<dmy_struct> dmy(nsteps);
+  for (int r = 0; r < nsteps; r++) {
+    memset(&dmy[r], 0, sizeof(dmy_struct));
+    dmy[r].hour = (r * dt) % 24; dmy[r].day = 1 + (r * dt) / 24; dmy[r].day_in_year = dmy[r].day; dmy[r].month = 1; dmy[r].year = 2001;
+  }
+  std::vector<double> col((size_t)VIC_NRAW * nfile);
+  for (int c = 0; c < nc; c++) {
+    soil_con_struct sc;
+    fill_soil_con(h, c, &sc);
+    /* what MTCLIM reads besides (its estimates of shortwave / vapour pressure are not used when both are supplied; tskc is
+     * not on the path) */
+    sc.lng = -120.f; sc.time_zone_lng = -120.f; sc.slope = 0; sc.aspect = 0; sc.ehoriz = 0; sc.whoriz = 0; sc.annual_prec = 800.;
+    sc.cell_area = 3.6e7;
+    VicrefForcingSource src;
+    for (int t = 0; t < N_FORCING_TYPES; t++) src.data[t] = NULL;
+    src.nrec = nfile;
+    for (int i = 0; i < VIC_NRAW; i++) {
+      for (int k = 0; k < nfile; k++) col[(size_t)i * nfile + k] = file[((size_t)raws[i] * nfile + k) * nc + c];
+      src.data[types[i]] = &col[(size_t)i * nfile];
+    }
+    atmos_data_struct *atmos = (atmos_data_struct *)calloc(nsteps, sizeof(atmos_data_struct));
+    for (int r = 0; r < nsteps; r++) { atmos_data_struct *a = make_atmos(NR); atmos[r] = *a; free(a); }
+    vicref_forcing_source = &src;
+    FILE *infile[2] = {NULL, NULL};
+    int ncids[2] = {0, 0};
+    int rc = 0;
+    try { initialize_atmos(atmos, dmy.data(), infile, ncids, &sc, &st); } catch (...) { rc = -2; }
+    vicref_forcing_source = NULL;
+    for (int r = 0; r < nsteps && rc == 0; r++) {
+      const atmos_data_struct &a = atmos[r];
+      for (int j = 0; j <= NR; j++) {
+        double *f = forcing + ((size_t)r * VIC_NFORCE * (NR + 1)) * nc;
+#define PUTF(v, x) f[((size_t)(v) * (NR + 1) + j) * nc + c] = (x)
+        PUTF(VIC_F_AIR_TEMP, a.air_temp[j]); PUTF(VIC_F_PREC, a.prec[j]); PUTF(VIC_F_PRESSURE, a.pressure[j]); PUTF(VIC_F_VP, a.vp[j]);
+        PUTF(VIC_F_VPD, a.vpd[j]); PUTF(VIC_F_DENSITY, a.density[j]); PUTF(VIC_F_SHORTWAVE, a.shortwave[j]);
+        PUTF(VIC_F_LONGWAVE, a.longwave[j]); PUTF(VIC_F_WIND, a.wind[j]);
+#undef PUTF
+        snowflag[((size_t)r * (NR + 1) + j) * nc + c] = a.snowflag[j] ? 1 : 0;
+      }
+    }
+    for (int r = 0; r < nsteps; r++) {
+      atmos_data_struct &a = atmos[r];
+      free(a.air_temp); free(a.channel_in); free(a.density); free(a.longwave); free(a.prec); free(a.pressure); free(a.shortwave);
+      free(a.snowflag); free(a.tskc); free(a.vp); free(a.vpd); free(a.wind);
+    }
+    free(atmos);
+    free(sc.BandElev); free(sc.AreaFract); free(sc.Pfactor); free(sc.Tfactor); free(sc.AboveTreeLine);
+    if (rc) return rc;
   }
   return 0;
 }

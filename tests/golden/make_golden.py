@@ -72,11 +72,26 @@ def make_gmb():
         print("gmb_%s" % name, eq[:, 0])
 
 
+def make_forcing_derive():
+    """atmos[rec] as the reference's initialize_atmos derives it from in-memory forcing records (tests/test_forcing_stream.py)."""
+    from tests.test_forcing_stream import DERIVE_CASES, derive_case
+    for name in sorted(DERIVE_CASES):
+        d, file, raw, force_dt, min_wind, plapse = derive_case(name)
+        ref = RefModel(d, "plain")
+        f, sf = ref.derive_forcing(file, force_dt, min_wind, plapse)
+        ref.close()
+        np.savez_compressed(os.path.join(HERE, "forcing_derive_%s.npz" % name), records=file, forcing=f, snowflag=sf)
+        print("forcing_derive_%s" % name, f.shape)
+
+
 def main():
     only = sys.argv[1:]                   # optional: the trajectory fixtures to (re)generate, by name
+    if only == ["forcing_derive"]:
+        return make_forcing_derive()
     if not only:
         make_pure()
         make_gmb()
+        make_forcing_derive()
     for name, (kw, variant, ncell, ntile, glacier, nsteps, doy, stride) in SCENARIOS.items():
         if only and name not in only:
             continue

@@ -10,7 +10,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def golden_names():
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("pure_", "gmb_"))]      # pure_*.npz: per-function vectors, tests/pure_inputs.py
+    return [n for n in names if not n.startswith(("pure_", "gmb_", "forcing_derive_"))]      # pure_*.npz: per-function vectors, tests/pure_inputs.py
 
 
 def load_golden(name):

@@ -44,6 +44,69 @@ def test_oracle_derivation_reproduces_the_synthetic_table(kw, oracle_lib):
     assert rel_diff(f3[:, C["VIC_F_DENSITY"], 0], 0.003486 * pr / (275.0 + T), 1e-12).max() < 1e-14
 
 
+# (options, forcing-file time step, min wind, PLAPSE): hourly forcing with one sub-step per step (the bench configs), with three
+# sub-steps per step (sub-index NR), 3-hourly records for a daily step with 3-hourly snow steps, and the non-PLAPSE density
+DERIVE_CASES = {
+    "hourly": (dict(FULL_ENERGY=1, Nband=3), 1, 0.3, 1),
+    "3hourly_step_hourly_substeps_vic412": (dict(FULL_ENERGY=1, dt=3, snow_step=1, Nband=2, TEMP_TH_TYPE=0), 1, 0.3, 1),
+    "daily_step_3hourly_records": (dict(FULL_ENERGY=0, dt=24, snow_step=3), 3, 0.25, 1),
+    "hourly_no_plapse": (dict(FULL_ENERGY=1, Nband=3), 1, 0.0, 0),
+}
+
+
+def derive_case(name, ncell=7, ndays=3):
+    """(domain, file records [VIC_NRAW][nfile][ncell] in file units, hourly raw table as vicgpu_prefetch_forcing_raw takes it)."""
+    kw, force_dt, min_wind, plapse = DERIVE_CASES[name]
+    opt = abi.default_options(**kw)
+    d = domain.make_domain(ncell, opt, ntile=2)
+    nfile, nsteps = ndays * 24 // force_dt, ndays * 24 // opt.dt
+    rng = np.random.default_rng(sorted(DERIVE_CASES).index(name) + 11)
+    hrs = (np.arange(nfile) * force_dt)[:, None]
+    file = np.zeros((C["VIC_NRAW"], nfile, d.ncell))
+    file[C["VIC_RAW_AIR_TEMP"]] = -2 + 6 * np.sin(2 * np.pi * (hrs - 9) / 24) + rng.normal(0, 1, (nfile, d.ncell))
+    file[C["VIC_RAW_PREC"]] = np.where(rng.uniform(size=(nfile, d.ncell)) < 0.3, rng.uniform(0, 3, (nfile, d.ncell)), 0.0)
+    file[C["VIC_RAW_PRESSURE_KPA"]] = 85 + rng.normal(0, 0.5, (nfile, d.ncell))
+    file[C["VIC_RAW_VP_KPA"]] = 0.45 + rng.uniform(-0.2, 0.4, (nfile, d.ncell))          # partly above saturation: vpd clips
+    file[C["VIC_RAW_SHORTWAVE"]] = np.maximum(0, 400 * np.sin(2 * np.pi * (hrs - 6) / 24)) * rng.uniform(0.5, 1, (nfile, d.ncell))
+    file[C["VIC_RAW_LONGWAVE"]] = 250 + rng.normal(0, 10, (nfile, d.ncell))
+    file[C["VIC_RAW_WIND"]] = rng.uniform(0.0, 4.0, (nfile, d.ncell))                     # partly below the floor
+    # the hourly table: what initialize_atmos makes of the records before it aggregates them (local_forcing_data,
+    # initialize_atmos.c:352-392): a record's value in each of its hours, amounts divided by the record length
+    hourly = np.repeat(file, force_dt, axis=1)
+    hourly[C["VIC_RAW_PREC"]] = np.repeat(file[C["VIC_RAW_PREC"]] / force_dt, force_dt, axis=0)
+    raw = np.ascontiguousarray(hourly.reshape(C["VIC_NRAW"], nsteps, opt.dt, d.ncell).transpose(1, 0, 2, 3))
+    return d, file, raw, force_dt, min_wind, plapse
+
+
+@pytest.mark.parametrize("name", sorted(DERIVE_CASES))
+def test_oracle_derivation_equals_reference_initialize_atmos(name, oracle_lib):
+    """The reference's own initialize_atmos (initialize_atmos.c:7-1349, MTCLIM included) run on forcing records held in
+    memory -- the harness only plays read_atmos_data -- against the oracle's derivation from the hourly table: every value of
+    atmos[rec] and every snowflag, bit for bit."""
+    if not oracle_lib.have_ref("plain"):
+        pytest.skip("reference build not present (oracle/_ref)")
+    d, file, raw, force_dt, min_wind, plapse = derive_case(name)
+    ref = oracle_lib.RefModel(d, "plain")
+    fr, sr = ref.derive_forcing(file, force_dt, min_wind, plapse)
+    ref.close()
+    fo, so = oracle_lib.OracleModel(d).derive_forcing(raw, min_wind, plapse)
+    assert np.array_equal(sr, so)
+    assert np.array_equal(fr, fo), worst(fr.reshape(-1, d.ncell), fo.reshape(-1, d.ncell), "VIC_F_", 1e-300)[1]
+    assert (fr[:, C["VIC_F_VPD"]] == 0).any() and sr.any()
+
+
+@pytest.mark.parametrize("name", sorted(DERIVE_CASES))
+def test_oracle_derivation_equals_reference_fixture(name, oracle_lib):
+    """The same comparison against the committed outputs of the reference (tests/golden/forcing_derive_*.npz, written by
+    tests/golden/make_golden.py from the run above): what travels to the GPU box."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "forcing_derive_%s.npz" % name))
+    d, file, raw, force_dt, min_wind, plapse = derive_case(name)
+    assert np.array_equal(z["records"], file)
+    fo, so = oracle_lib.OracleModel(d).derive_forcing(raw, min_wind, plapse)
+    assert np.array_equal(z["snowflag"], so) and np.array_equal(z["forcing"], fo)
+
+
 def _state0(d, f):
     return init_state.initial_state(d, f[0])
 

@@ -75,6 +75,9 @@ constexpr double NODE_NEWTON_TOL = 1.e-8;                                       
 #ifndef VIC_NEWTON_PREDICTOR
 #define VIC_NEWTON_PREDICTOR 1
 #endif
+#ifndef VIC_NOSE_CLASSIFY
+#define VIC_NOSE_CLASSIFY 1
+#endif
 #ifndef VIC_PREDICT_TOL2
 #define VIC_PREDICT_TOL2 1.e-7
 #endif
@@ -125,7 +128,9 @@ VIC_DEV double node_visit(bool sweeping, bool frozen_on, bool EXP_TRANS, const N
   const bool nose = NODE1 && fabs(Tdn - Tup) > 5.;
 #endif
   if (!NEWTON) steep = fz;
+#if !VIC_NOSE_CLASSIFY
   else if (NODE1) steep = fz && nose;
+#endif
   double x = N / K.S;                       // unfrozen node, or root in T >= 0 where ice = 0
   failed = false;
   PROF_WAVE(18); PROF_VOTE(19, fz);
@@ -215,6 +220,30 @@ VIC_DEV double node_visit(bool sweeping, bool frozen_on, bool EXP_TRANS, const N
     }
     PROF_ADD(23, t_nw);
   }
+#if VIC_NOSE_CLASSIFY
+  // ---- node 1, cold nose (soil_thermal_eqn.c:57-72, 84-93).  With |TL - TU| > 5 K the reference drops the flux term
+  // ft1 = B (TL - TU) from the residual where ft1 < 0, T < min(TL, TU), ft2(T) > 0 and |ft1| > |ft2(T)|; ft2 decreases in T, so
+  // that is an interval Tb < T < Thi below both neighbours (ft2 > 0 holds there by itself; EXP_TRANS: below its own zero as
+  // well), on which the residual is g(T) + |ft1| instead of g(T) = N - S T + E ice(T).  g decreases, so wherever the root
+  // r of g lies at or above Thi the residual has the sign of g everywhere and r is its only sign change: what the Newton
+  // iteration above has found is what the reference's Brent iteration converges to.  Only when r lies below Thi (the node
+  // would end up colder than both neighbours) can the two branches offer several sign changes; those visits replay the
+  // reference's iteration on the reference's residual.  (A margin of 1e-6 K sends borderline roots to the replay.)
+  if (NEWTON && NODE1) {
+    const double ft1n = K.B * (Tdn - Tup);
+    bool sp = fz && nose && ft1n < 0;
+    if (__any(sp)) {
+      double Thi = fmin(Tdn, Tup), Tb;
+      if (!EXP_TRANS) Tb = (K.C * Tdn + K.D * Tup + ft1n) / (K.C + K.D);
+      else {
+        const double num = K.C * (Tdn + Tup) - K.D * (Tdn - Tup);
+        Thi = fmin(Thi, num / (2. * K.C));
+        Tb = (num + ft1n) / (2. * K.C);
+      }
+      steep = sp && Tb < Thi && !failed && x < Thi + 1.e-6;
+    }
+  }
+#endif
   // ---- the reference's Brent iteration (root_brent.c:97-337) on the reference's residual
   if (NODE1 || !NEWTON) {
     if (__any(steep)) {

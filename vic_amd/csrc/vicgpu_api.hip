@@ -1810,8 +1810,10 @@ __global__ __launch_bounds__(256) void vic_derive_forcing(const FArgs a) {
   if (NF > 1) {                                                                       // x[NR] = sum / (float)NF; prec[NR] = sum
     const double n = (double)(float)NF;
     F(VIC_F_AIR_TEMP, a.NR) = sT / n; F(VIC_F_PREC, a.NR) = sP; F(VIC_F_PRESSURE, a.NR) = sPr / n; F(VIC_F_VP, a.NR) = sVp / n;
-    F(VIC_F_VPD, a.NR) = sVpd / n; F(VIC_F_DENSITY, a.NR) = sD / n; F(VIC_F_SHORTWAVE, a.NR) = sSw / n; F(VIC_F_LONGWAVE, a.NR) = sLw / n;
+    F(VIC_F_VPD, a.NR) = sVpd / n; F(VIC_F_SHORTWAVE, a.NR) = sSw / n; F(VIC_F_LONGWAVE, a.NR) = sLw / n;
     F(VIC_F_WIND, a.NR) = sW / n;
+    // density[NR] is derived from pressure[NR] and air_temp[NR] like every other slot (initialize_atmos.c:984-998), not averaged
+    F(VIC_F_DENSITY, a.NR) = a.plapse ? (sPr / n) / (287.0 * (KELVIN + sT / n)) : 0.003486 * (sPr / n) / (275.0 + sT / n);
     sf[(size_t)a.NR * nc] = any_snow ? 1 : 0;
   }
 #undef RAW
@@ -1872,7 +1874,8 @@ static int prefetch_impl(vicgpu_ctx* c, int nsteps, const double* forcing, const
     HIPCHK(c, upload(c, sl, sl.d_raw, raw, rbytes, 0));
     FArgs a;
     a.nsteps = nsteps; a.ncell = c->ncell; a.dt = c->o.dt; a.snow_step = c->o.snow_step; a.NF = c->o.NF; a.NR = c->o.NR;
-    a.temp_th_type = c->o.TEMP_TH_TYPE; a.Nband = c->o.Nband; a.Nnode = c->o.Nnode; a.plapse = plapse; a.min_wind = min_wind;
+    a.temp_th_type = c->o.TEMP_TH_TYPE; a.Nband = c->o.Nband; a.Nnode = c->o.Nnode; a.plapse = plapse;
+    a.min_wind = (double)(float)min_wind;        // options.MIN_WIND_SPEED is a float (vicNl_def.h:713)
     a.raw = sl.d_raw; a.cell_params = c->d_cp; a.forcing = sl.d_f; a.snowflag = sl.d_s;
     const size_t n = (size_t)nsteps * c->ncell;
     hipLaunchKernelGGL(vic_derive_forcing, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->copy_stream, a);

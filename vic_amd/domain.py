@@ -523,5 +523,7 @@ def make_forcing(d, step0, nsteps, start_doy=1, cold=0.0):
                     f[i, v, NR] = f[i, v, :NF].sum(axis=0)
                 else:
                     f[i, v, NR] = f[i, v, :NF].mean(axis=0)
+            # density[NR] comes from pressure[NR] and air_temp[NR] like every sub-step's (initialize_atmos.c:984-998)
+            f[i, C["VIC_F_DENSITY"], NR] = f[i, C["VIC_F_PRESSURE"], NR] / (287.0 * (f[i, C["VIC_F_AIR_TEMP"], NR] + 273.15))
             sflag[i, NR] = sflag[i, :NF].max(axis=0)
     return np.ascontiguousarray(f), np.ascontiguousarray(sflag), dmy
