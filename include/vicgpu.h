@@ -23,11 +23,10 @@
  * Option coverage: Nlayer = 3, DIST_PRCP = FALSE
  * (Ndist = 1, mu = 1), no lakes, no EXCESS_ICE / SPATIAL_FROST / SPATIAL_SNOW /
  * QUICK_FS / LOW_RES_MOIST / CLOSE_ENERGY (all compiled out in the reference,
- * user_def.h:36-92).  CORRPREC, IMPLICIT (finite-difference soil profile, node-array
+ * user_def.h:36-92).  CORRPREC, BLOWING, IMPLICIT (finite-difference soil profile, node-array
  * freezing parameters: frozen_compat = 0) and QUICK_SOLVE (with NOFLUX and EXP_TRANS off)
- * are implemented.  The options struct also carries BLOWING so that a binding passes the
- * reference's settings through unchanged: what the device code does not implement (see
- * vicgpu_create) is REJECTED with VICGPU_ERR_UNSUPPORTED, never silently replaced.
+ * are implemented.  What the device code does not implement (see vicgpu_create) is
+ * REJECTED with VICGPU_ERR_UNSUPPORTED, never silently replaced.
  */
 #ifndef VICGPU_H_
 #define VICGPU_H_
@@ -38,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VICGPU_ABI_VERSION 2
+#define VICGPU_ABI_VERSION 3
 
 #define VIC_NLAYER        3    /* MAX_LAYERS, user_def.h:95 */
 #define VIC_MAX_NODES    18    /* device build limit for options.Nnode (reference MAX_NODES = 50, user_def.h:96) */
@@ -100,7 +99,7 @@ typedef struct vicgpu_options {
   int CORRPREC;             /* gauge-undercatch correction of precipitation (correct_precip.c, full_energy.c:188-194) */
   int IMPLICIT;             /* options.IMPLICIT: Newton-Raphson soil heat solver (frozen_soil.c:229-301, newt_raph_func_fast.c),
                                the explicit solver as its fallback; rejected with QUICK_FLUX or frozen_compat */
-  int BLOWING;              /* options.BLOWING: blowing-snow sublimation (CalcBlowingSnow.c); rejected when set */
+  int BLOWING;              /* options.BLOWING: sublimation from blowing snow (CalcBlowingSnow.c), once per snow sub-step */
   int QUICK_SOLVE;          /* options.QUICK_SOLVE (calc_surf_energy_bal.c:289-314, 400-475): ignored with QUICK_FLUX (as in the
                                reference); rejected together with NOFLUX, EXP_TRANS or IMPLICIT */
   int NODE_SOLVER;          /* VIC_NODE_SOLVER_*: how the frozen-node heat balance (soil_thermal_eqn.c) is solved -- not a
@@ -189,7 +188,9 @@ enum { CPB_AREAFRACT = 0, CPB_TFACTOR, CPB_PFACTOR, CPB_BANDELEV, CPB_ABOVETREEL
  * veg_con_struct + HRU meta (vicNl_def.h:1017-1029, 1374-1388).
  * int table int[HPI_NROW][nhru], double table double[HPD_NROW][nhru]. */
 enum { HPI_CELL = 0, HPI_BAND, HPI_VEG_INDEX, HPI_VEG_CLASS, HPI_IS_GLACIER, HPI_IS_ARTIFICIAL_BARE, HPI_NROW };
-enum { HPD_CV = 0, HPD_ROOT0, HPD_ROOT1, HPD_ROOT2, HPD_NROW };
+/* HPD_SIGMA_SLOPE, HPD_LAG_ONE, HPD_FETCH: veg_con.sigma_slope / lag_one / fetch (float in the reference, read_vegparam.c),
+ * read by the blowing-snow model only (options.BLOWING) */
+enum { HPD_CV = 0, HPD_ROOT0, HPD_ROOT1, HPD_ROOT2, HPD_SIGMA_SLOPE, HPD_LAG_ONE, HPD_FETCH, HPD_NROW };
 
 /* ---------------------------------------------------------------- HRU state
  * SURVEY.md Appendix A.  double[VICGPU_SD_NROW(Nnode)][nhru], int[SI_NROW][nhru].

@@ -104,6 +104,8 @@ void vicgpu_binding_pack_domain(const ProgramState *state, const std::vector<cel
     t.hpi[(size_t)HPI_IS_GLACIER * nh + g] = u.isGlacier ? 1 : 0; t.hpi[(size_t)HPI_IS_ARTIFICIAL_BARE * nh + g] = u.isArtificialBareSoil ? 1 : 0;
     t.hpd[(size_t)HPD_CV * nh + g] = u.veg_con.Cv;
     for (int l = 0; l < 3; l++) t.hpd[(size_t)(HPD_ROOT0 + l) * nh + g] = u.veg_con.root[l];
+    t.hpd[(size_t)HPD_SIGMA_SLOPE * nh + g] = u.veg_con.sigma_slope; t.hpd[(size_t)HPD_LAG_ONE * nh + g] = u.veg_con.lag_one;
+    t.hpd[(size_t)HPD_FETCH * nh + g] = u.veg_con.fetch;
   }
 }
 

@@ -151,6 +151,7 @@ typedef struct orc_hru_s {
   /* parameters */
   int cell, band, veg_index, veg_class, is_glacier, is_artificial_bare;
   double Cv, root[3];
+  float sigma_slope, lag_one, fetch;       /* veg_con (vicNl_def.h:1023-1027): blowing snow only */
   /* state + per-step outputs */
   orc_layer layer[3];
   orc_energy energy;
@@ -191,6 +192,11 @@ static inline const double *orc_veg(const orc_model *m, int idx) { return m->veg
 
 /* ---- orc_base.c ---- */
 double orc_svp(double T);
+/* orc_blowing.c: CalcBlowingSnow.c:101-310 */
+double orc_calc_blowing_snow(double Dt, double Tair, int LastSnow, double SurfaceLiquidWater, double Wind, double Ls, double AirDens,
+                             double EactAir, double ZO, double Zrh, double snowdepth, float lag_one, float sigma_slope,
+                             double Tsnow, int isArtificialBareSoil, float fe, double displacement, double roughness,
+                             double *TotalTransport);
 double orc_svp_slope(double T);
 double orc_calc_rc(double rs, double net_short, float RGL, double tair, double vpd, double lai, double gsm_inv, int ref_crop);
 double orc_penman(double tair, double elevation, double rad, double vpd, double ra, double rc, double rarc);

@@ -93,7 +93,16 @@ static int orc_surface_fluxes(const orc_model *m, orc_hru *h, const orc_soil *sc
     Tcanopy = Tair;
     VPcanopy = atmos->vp[hidx];
     VPDcanopy = atmos->vpd[hidx];
-    step_snow.blowing_flux = 0.0;                                                  /* BLOWING off, :452-453 */
+    if (!overstory && m->opt.BLOWING && step_snow.swq > 0.) {                      /* surface_fluxes.c:439-453 */
+      double Ls = (677. - 0.07 * step_snow.surf_temp) * 4.1868 * 1000.0;
+      step_snow.blowing_flux = orc_calc_blowing_snow((double)step_dt, Tair, step_snow.last_snow, step_snow.surf_water,
+                                                     wind_speed->v[ORC_SNOW_COVERED], Ls, atmos->density[hidx], atmos->vp[hidx],
+                                                     roughness->v[ORC_SNOW_COVERED], ref_height->v[ORC_SNOW_COVERED], step_snow.depth,
+                                                     h->lag_one, h->sigma_slope, step_snow.surf_temp, h->is_artificial_bare, h->fetch,
+                                                     displacement->v[ORC_CANOPY], roughness->v[ORC_CANOPY], &step_snow.transport);
+      if ((int)step_snow.blowing_flux == ORC_ERROR) return -1;
+      step_snow.blowing_flux *= step_dt * ORC_SECPHOUR / ORC_RHO_W;
+    } else step_snow.blowing_flux = 0.0;
     UnderStory = ORC_NCASE;
     snow_grnd_flux = -snow_flux;
 
@@ -509,6 +518,8 @@ int vicorc_set_domain(void *hv, int ncell, int nhru, const double *cp, const int
     u->is_glacier = hpi[(size_t)HPI_IS_GLACIER * nhru + g]; u->is_artificial_bare = hpi[(size_t)HPI_IS_ARTIFICIAL_BARE * nhru + g];
     u->Cv = hpd[(size_t)HPD_CV * nhru + g];
     for (l = 0; l < 3; l++) u->root[l] = (double)(float)hpd[(size_t)(HPD_ROOT0 + l) * nhru + g];
+    u->sigma_slope = (float)hpd[(size_t)HPD_SIGMA_SLOPE * nhru + g]; u->lag_one = (float)hpd[(size_t)HPD_LAG_ONE * nhru + g];
+    u->fetch = (float)hpd[(size_t)HPD_FETCH * nhru + g];
   }
   return 0;
 }

@@ -511,7 +511,16 @@ int orc_surface_fluxes_glac(const orc_model *m, orc_hru *h, const orc_soil *sc, 
     step_out_snow = snowfall;
     Tgrnd = ORC_GLAC_TEMP;
     VPDcanopy = 0.;
-    step_snow.blowing_flux = 0.0;
+    if (m->opt.BLOWING && step_snow.swq > 0.) {                                     /* surface_fluxes_glac.c:260-274 */
+      double Ls = (677. - 0.07 * step_snow.surf_temp) * 4.1868 * 1000.0;
+      step_snow.blowing_flux = orc_calc_blowing_snow((double)step_dt, Tair, step_snow.last_snow, step_snow.surf_water,
+                                                     wind_speed->v[ORC_SNOW_COVERED], Ls, atmos->density[hidx], atmos->vp[hidx],
+                                                     roughness->v[ORC_SNOW_COVERED], ref_height->v[ORC_SNOW_COVERED], step_snow.depth,
+                                                     h->lag_one, h->sigma_slope, step_snow.surf_temp, h->is_artificial_bare, h->fetch,
+                                                     displacement->v[ORC_CANOPY], roughness->v[ORC_CANOPY], &step_snow.transport);
+      if ((int)step_snow.blowing_flux == ORC_ERROR) return -1;
+      step_snow.blowing_flux *= step_dt * ORC_SECPHOUR / ORC_RHO_W;
+    } else step_snow.blowing_flux = 0.0;
     temp_aero_resist = aero_resist[ORC_NPET];
     ra_used[0] = h->aero_resist_surface;
     ra_used[1] = h->aero_resist_overstory;

@@ -117,6 +117,7 @@ void *vicref_create(const vicgpu_options *opt) {
   s.options.FROZEN_SOIL = opt->FROZEN_SOIL;
   s.options.QUICK_FLUX = opt->QUICK_FLUX;
   s.options.CORRPREC = opt->CORRPREC;
+  s.options.BLOWING = opt->BLOWING;
   s.options.NOFLUX = opt->NOFLUX;
   s.options.IMPLICIT = opt->IMPLICIT;
   s.options.QUICK_SOLVE = opt->QUICK_SOLVE;
@@ -285,7 +286,8 @@ int vicref_set_domain(void *hv, int ncell, int nhru, const double *cell_params, 
       for (int l = 0; l < 3; l++) hru.veg_con.root[l] = (float)hpd[(size_t)(HPD_ROOT0 + l) * nhru + g];
       hru.veg_con.vegIndex = hpi[(size_t)HPI_VEG_INDEX * nhru + g];
       hru.veg_con.vegClass = hpi[(size_t)HPI_VEG_CLASS * nhru + g];
-      hru.veg_con.sigma_slope = 0.08f; hru.veg_con.lag_one = 0.95f; hru.veg_con.fetch = 1000.f;
+      hru.veg_con.sigma_slope = (float)hpd[(size_t)HPD_SIGMA_SLOPE * nhru + g]; hru.veg_con.lag_one = (float)hpd[(size_t)HPD_LAG_ONE * nhru + g];
+      hru.veg_con.fetch = (float)hpd[(size_t)HPD_FETCH * nhru + g];
       hru.veg_con.LAKE = 0;
       hru.veg_con.zone_depth = NULL; hru.veg_con.zone_fract = NULL;
       hru.init_STILL_STORM = 0; hru.init_DRY_TIME = 0;

@@ -4,6 +4,7 @@ import os
 import numpy as np
 
 from vic_amd import abi, domain
+from vic_amd.abi import C
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -27,7 +28,12 @@ def load_golden(name):
     d.veglib = np.ascontiguousarray(z["veglib"])
     d.cell_params = np.ascontiguousarray(z["cell_params"])
     d.hru_iparams = np.ascontiguousarray(z["hru_iparams"].astype(np.int32))
-    d.hru_dparams = np.ascontiguousarray(z["hru_dparams"])
+    hpd = z["hru_dparams"]
+    if hpd.shape[0] < C["HPD_NROW"]:      # fixtures written before the blowing-snow rows existed: the values the harness used then
+        pad = np.zeros((C["HPD_NROW"], hpd.shape[1])); pad[:hpd.shape[0]] = hpd
+        pad[C["HPD_SIGMA_SLOPE"]] = np.float32(0.08); pad[C["HPD_LAG_ONE"]] = np.float32(0.95); pad[C["HPD_FETCH"]] = np.float32(1000.0)
+        hpd = pad
+    d.hru_dparams = np.ascontiguousarray(hpd)
     d.cell_hru_offset = np.ascontiguousarray(z["cell_hru_offset"].astype(np.int32))
     d.cell_hru_list = np.ascontiguousarray(z["cell_hru_list"].astype(np.int32))
     d.init_moist = np.ascontiguousarray(z["init_moist"])

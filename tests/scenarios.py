@@ -48,6 +48,14 @@ OPTION_BRANCHES = {
                              nsteps=200, doy=120, tweak="zero_area_glacier"),
     "glacier_dynamics_frozen": dict(kw=dict(FROZEN, Nband=2, GLACIER_DYNAMICS=1), variant="fixed", ncell=4, ntile=2, glacier=True,
                                     nsteps=100, doy=100, tweak="zero_area_glacier"),
+    # BLOWING: sublimation from blowing snow (CalcBlowingSnow.c), once per snow sub-step for HRUs without overstory and for
+    # glacier HRUs; strong wind, so that the saltation threshold is exceeded in part of the wind distribution
+    "blowing": dict(kw=dict(FULL_ENERGY=1, BLOWING=1), variant="plain", ncell=6, ntile=3, nsteps=160, doy=350, tweak="windy"),
+    "blowing_frozen": dict(kw=dict(FROZEN, BLOWING=1), variant="fixed", ncell=4, ntile=2, nsteps=80, doy=20, tweak="windy"),
+    "blowing_glacier": dict(kw=dict(FULL_ENERGY=1, Nband=3, BLOWING=1), variant="plain", ncell=4, ntile=2, glacier=True, nsteps=120, doy=30,
+                            tweak="windy"),
+    "blowing_wb_daily": dict(kw=dict(FULL_ENERGY=0, dt=24, snow_step=3, BLOWING=1), variant="plain", ncell=6, ntile=2, nsteps=40, doy=340,
+                             tweak="windy"),
 }
 
 # IMPLICIT soil heat solution (newt_raph_func_fast.c, frozen_soil.c:229-301,540-803): Newton iteration with the explicit
@@ -87,6 +95,8 @@ def build(name, nsteps=None):
         cells = np.arange(d.ncell) % 3 == 1
         for s in range(5, n, 7):
             f[s, sw][:, cells] = 60000.0
+    elif tw == "windy":
+        f[:, C["VIC_F_WIND"]] *= 3.5
     elif tw == "zero_area_glacier":
         # glacier HRUs of every second cell lose their area (Cv = 0): skipped without GLACIER_DYNAMICS, run with it
         isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0

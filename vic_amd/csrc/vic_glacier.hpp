@@ -218,7 +218,8 @@ struct GlacWork {
 template <int NN>
 VIC_DEV bool surface_fluxes_glac(const Opt& o, const CellView& cv, const VegLib& vl, const Soil3& s3, const Forcing& fc, const Dmy& dmy,
                                  int veg_idx, int band, double BareAlbedo, const Vc* aero_pet, const Vc& Ra, const Vc& U, const Vc& zref,
-                                 const Vc& z0, HruWork<NN>& w, Glac& gl, double NetLongUnder_prev, GlacEnergy& ge,
+                                 const Vc& z0, const Vc& disp, const double* blow /* sigma_slope, lag_one, fetch, is_art_bare */,
+                                 HruWork<NN>& w, Glac& gl, double NetLongUnder_prev, GlacEnergy& ge,
                                  double& NetLongUnder_out, double& NetShortUnder_out, double& ShortUnderIn_out) {
   Snow& snow = w.snow;
   bool ok = true;
@@ -246,7 +247,14 @@ VIC_DEV bool surface_fluxes_glac(const Opt& o, const CellView& cv, const VegLib&
     double rainfall = gc[0] * rainOnly * cv.s(CP_PADJ_R);
     const double step_out_prec = snowfall + rainfall, step_out_rain = rainfall, step_out_snow = snowfall;
     const double Tgrnd = GLAC_TEMP, VPDcanopy = 0.;
-    snow.blowing_flux = 0.0;
+    if (o.BLOWING && snow.swq > 0.) {                                   // surface_fluxes_glac.c:260-274
+      const double Ls = (677. - 0.07 * snow.surf_temp) * 4.1868 * 1000.0;
+      const double bf = calc_blowing_snow((double)step_dt, Tair, snow.last_snow, snow.surf_water, U.v[SNOW_COVERED], Ls,
+                                          fc.v(VIC_F_DENSITY, hidx), fc.v(VIC_F_VP, hidx), z0.v[SNOW_COVERED], snow.depth, (float)blow[1],
+                                          (float)blow[0], blow[3] != 0.0, (float)blow[2], disp.v[CANOPY], z0.v[CANOPY]);
+      if ((int)bf == (int)ERROR_VAL) ok = false;
+      snow.blowing_flux = bf * step_dt * SECPHOUR / RHO_W;
+    } else snow.blowing_flux = 0.0;
     double ra_used[2] = {w.aero_resist_surface, w.aero_resist_overstory};
     snow.canopy_vapor_flux = 0; snow.vapor_flux = 0; snow.surface_flux = 0;
     double LongUnderIn = fc.v(VIC_F_LONGWAVE, hidx), ShortUnderIn = fc.v(VIC_F_SHORTWAVE, hidx);

@@ -373,7 +373,8 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
       const int slot = base + __popcll(idle & ((1ull << lane) - 1ull));
       if (!have && slot < n) {
         hru = profile_pick(a, bcount, slot);
-        const double* __restrict__ blk = a.pin + (size_t)hru * Nn * PREC;
+        // an item block starts on a 16-byte boundary (10 nodes x 11 doubles = 880 bytes): lets pairs of words load as one access
+        const double* __restrict__ blk = static_cast<const double*>(__builtin_assume_aligned(a.pin + (size_t)hru * Nn * PREC, 16));
         ps = a.pslot[hru];
         jl_lane = a.jl ? a.jl[hru] : jlast;
         frozen_on = blk[PR_AT0] != 0.0;

@@ -1,6 +1,7 @@
 // vic_step.hpp — one HRU step: full_energy's per-HRU body and surface_fluxes (device only, gfx950).
 #pragma once
 #include "vic_surface.hpp"
+#include "vic_blowing.hpp"
 
 namespace vic {
 
@@ -230,6 +231,7 @@ struct StepConst {
   Vc aero_pet[NPET];     // aero_pet[p].v = { snowFree, canopy, snowCovered, - } resistances of PET type p
   Vc Ra, U, disp, zref, z0;
   double surf_atten, bare_albedo, ice0, moist0, root[3];
+  double sigma_slope, lag_one, fetch;      // veg_con (float values): blowing snow only
   int veg_idx, band, is_art_bare, overstory;
 };
 
@@ -250,7 +252,7 @@ VIC_DEV void step_const_post_in(const StepConstPost& q, int UnderStory, StepCons
     C.Ra.v[k] = (k == CANOPY) ? q.Ra_canopy : ((k == UnderStory) ? q.Ra_under : 0.0);
     C.U.v[k] = 0; C.disp.v[k] = 0; C.zref.v[k] = 0; C.z0.v[k] = 0;
   }
-  C.surf_atten = 0; C.bare_albedo = 0; C.ice0 = 0; C.moist0 = 0;
+  C.surf_atten = 0; C.bare_albedo = 0; C.ice0 = 0; C.moist0 = 0; C.sigma_slope = 0; C.lag_one = 0; C.fetch = 0;
 }
 
 // surface_fluxes (surface_fluxes.c:17-956) with CLOSE_ENERGY FALSE (both closure loops execute once), Ndist 1.
@@ -336,7 +338,15 @@ VIC_DEV void sf_sub_pre(const Opt& o, const CellView& cv, const VegLib& vl, cons
   const double step_prec = fc.v(VIC_F_PREC, hidx) / 1.0 * cv.band(CPB_PFACTOR, C.band);
   const double Tcanopy = Tair;
   const double VPcanopy = fc.v(VIC_F_VP, hidx), VPDcanopy = fc.v(VIC_F_VPD, hidx);
-  snow.blowing_flux = 0.0;
+  // mass flux of blowing snow (surface_fluxes.c:439-453): once per sub-step, before the snow pack's energy balance
+  if (!C.overstory && o.BLOWING && snow.swq > 0.) {
+    const double Ls = (677. - 0.07 * snow.surf_temp) * 4.1868 * 1000.0;
+    const double bf = calc_blowing_snow((double)L.step_dt, Tair, snow.last_snow, snow.surf_water, C.U.v[SNOW_COVERED], Ls,
+                                        fc.v(VIC_F_DENSITY, hidx), fc.v(VIC_F_VP, hidx), C.z0.v[SNOW_COVERED], snow.depth, (float)C.lag_one,
+                                        (float)C.sigma_slope, C.is_art_bare, (float)C.fetch, C.disp.v[CANOPY], C.z0.v[CANOPY]);
+    if ((int)bf == (int)ERROR_VAL) L.ok = 0;
+    snow.blowing_flux = bf * L.step_dt * SECPHOUR / RHO_W;
+  } else snow.blowing_flux = 0.0;
   int UnderStory = NCASE;
   // snow_grnd_flux = -snow_flux is overwritten inside snow_melt
   // per-iteration resets (surface_fluxes.c:501-532)

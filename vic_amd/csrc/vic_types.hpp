@@ -96,7 +96,7 @@ VIC_DEV bool is_error(double x) { return x <= -998.0; }   // RootBrent::resultIs
 struct Opt {
   int Nnode, Nband, dt, snow_step, NF, NR;
   int FULL_ENERGY, FROZEN_SOIL, QUICK_FLUX, NOFLUX, EXP_TRANS, GRND_FLUX_TYPE, TFALLBACK, AERO_RESIST_CANSNOW,
-      SNOW_ALBEDO, SNOW_DENSITY, TEMP_TH_TYPE, GLACIER_ID, GLACIER_DYNAMICS, frozen_compat, nveg_types, CORRPREC, IMPLICIT, QUICK_SOLVE;
+      SNOW_ALBEDO, SNOW_DENSITY, TEMP_TH_TYPE, GLACIER_ID, GLACIER_DYNAMICS, frozen_compat, nveg_types, CORRPREC, IMPLICIT, QUICK_SOLVE, BLOWING;
   double wind_h;
 };
 

@@ -94,18 +94,33 @@ struct KArgs {
 #ifndef VIC_CTX_AOS
 #define VIC_CTX_AOS 0
 #endif
-#if VIC_CTX_AOS
-constexpr size_t CTX_WORD_STRIDE = 1;     // [hru][word]: one HRU's context is one contiguous block
-#else
-constexpr size_t CTX_WORD_STRIDE = 64;    // [hru / 64][word][hru % 64]
+#ifndef VIC_CTX_PAIR
+#define VIC_CTX_PAIR 1
 #endif
+// Word W of HRU g:  AOS   [hru][word]                        one HRU's context is one contiguous block
+//                   PAIR  [hru / 64][word / 2][hru % 64][2]  a wave's slab; a lane's words come in adjacent pairs, so two
+//                                                            consecutive words of a struct are one 16-byte access per lane
+//                                                            (128-byte lines per 8 lanes; 8-byte-per-lane rows run the
+//                                                            load path at half its rate)
+//                   else  [hru / 64][word][hru % 64]
 struct CtxRef {
   unsigned long long* p;    // word 0 of this HRU
   VIC_DEV static CtxRef at(unsigned long long* base, size_t words_per_hru, size_t g) {
 #if VIC_CTX_AOS
     return CtxRef{base + g * words_per_hru};
+#elif VIC_CTX_PAIR
+    return CtxRef{base + (g >> 6) * (((words_per_hru + 1) & ~(size_t)1) * 64) + (g & 63) * 2};
 #else
     return CtxRef{base + (g >> 6) * (words_per_hru * 64) + (g & 63)};
+#endif
+  }
+  VIC_DEV unsigned long long* word(size_t W) const {
+#if VIC_CTX_AOS
+    return p + W;
+#elif VIC_CTX_PAIR
+    return p + (W >> 1) * 128 + (W & 1);
+#else
+    return p + W * 64;
 #endif
   }
 };
@@ -115,18 +130,16 @@ VIC_DEV void ctx_put(const CtxRef& r, size_t word0, const T& v) {
   constexpr int NW = sizeof(T) / 8;
   unsigned long long tmp[NW];
   __builtin_memcpy(tmp, &v, sizeof(T));
-  unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
-  for (int i = 0; i < NW; i++) q[(size_t)i * CTX_WORD_STRIDE] = tmp[i];
+  for (int i = 0; i < NW; i++) *r.word(word0 + i) = tmp[i];
 }
 template <class T>
 VIC_DEV void ctx_get(const CtxRef& r, size_t word0, T& v) {
   static_assert(sizeof(T) % 8 == 0 && std::is_trivially_copyable<T>::value, "context structs are arrays of 8-byte words");
   constexpr int NW = sizeof(T) / 8;
   unsigned long long tmp[NW];
-  const unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
-  for (int i = 0; i < NW; i++) tmp[i] = q[(size_t)i * CTX_WORD_STRIDE];
+  for (int i = 0; i < NW; i++) tmp[i] = *r.word(word0 + i);
   __builtin_memcpy(&v, tmp, sizeof(T));
 }
 // SurfEBConst / SurfEBMut are parked group by group (vic_surface.hpp): word ranges of the groups
@@ -151,13 +164,12 @@ constexpr size_t CW_SV_ITER = offsetof(SurfSolve, Tsurf) / 8;
 template <class T>
 VIC_DEV void ctx_put_words(const CtxRef& r, size_t word0, const T& v, int first, int last) {
   constexpr int NW = sizeof(T) / 8;
-  unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
   for (int i = 0; i < NW; i++)
     if (i >= first && i < last) {
       unsigned long long w;
       __builtin_memcpy(&w, reinterpret_cast<const char*>(&v) + 8 * i, 8);
-      q[(size_t)i * CTX_WORD_STRIDE] = w;
+      *r.word(word0 + i) = w;
     }
 }
 // word by word into the object (no whole-struct copy: the conditional group loads of the evaluation kernel must not make the
@@ -165,11 +177,10 @@ VIC_DEV void ctx_put_words(const CtxRef& r, size_t word0, const T& v, int first,
 template <class T>
 VIC_DEV void ctx_get_words(const CtxRef& r, size_t word0, T& v, int first, int last) {
   constexpr int NW = sizeof(T) / 8;
-  const unsigned long long* __restrict__ q = r.p + word0 * CTX_WORD_STRIDE;
 #pragma unroll
   for (int i = 0; i < NW; i++)
     if (i >= first && i < last) {
-      const unsigned long long w = q[(size_t)i * CTX_WORD_STRIDE];
+      const unsigned long long w = *r.word(word0 + i);
       __builtin_memcpy(reinterpret_cast<char*>(&v) + 8 * i, &w, 8);
     }
 }
@@ -485,6 +496,10 @@ VIC_DEV int hru_prologue(const KArgs& a, int g, const HruId& id, const CellView&
   C.veg_idx = veg_idx; C.band = id.band; C.is_art_bare = id.is_art_bare ? 1 : 0;
 #pragma unroll
   for (int l = 0; l < 3; l++) C.root[l] = (double)(float)a.hpd[(size_t)(HPD_ROOT0 + l) * nh + g];
+  if (o.BLOWING) {
+    C.sigma_slope = (double)(float)a.hpd[(size_t)HPD_SIGMA_SLOPE * nh + g]; C.lag_one = (double)(float)a.hpd[(size_t)HPD_LAG_ONE * nh + g];
+    C.fetch = (double)(float)a.hpd[(size_t)HPD_FETCH * nh + g];
+  } else { C.sigma_slope = 0; C.lag_one = 0; C.fetch = 0; }
   load_state<NN>(a, g, w, node_props);
   w.snow.vapor_flux = 0.; w.snow.canopy_vapor_flux = 0.;                  // full_energy.c:261-262
 
@@ -610,7 +625,8 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
     if constexpr (GLAC) {
       GlacEnergy ge;
       double nlu, nsu, sui;
-      ok = surface_fluxes_glac<NN>(o, cv, vl, s3, fc, a.dmy, C.veg_idx, C.band, C.bare_albedo, C.aero_pet, C.Ra, C.U, C.zref, C.z0, w, w.gl,
+      const double blow[4] = {C.sigma_slope, C.lag_one, C.fetch, (double)C.is_art_bare};
+      ok = surface_fluxes_glac<NN>(o, cv, vl, s3, fc, a.dmy, C.veg_idx, C.band, C.bare_albedo, C.aero_pet, C.Ra, C.U, C.zref, C.z0, C.disp, blow, w, w.gl,
                                    w.so.NetLongUnder, ge, nlu, nsu, sui);
       // hru.energy = step_energy + step averages (surface_fluxes_glac.c:485-526)
       SoilEnergy& so = w.so; SnowEnergy& se = w.se;
@@ -1520,7 +1536,6 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   if (opt->QUICK_FLUX && opt->Nnode != 3) return VICGPU_ERR_ARG;             // get_global_param.c:1151-1155
   if (opt->FROZEN_SOIL && opt->QUICK_FLUX) return VICGPU_ERR_ARG;            // get_global_param.c:376-381
   // options of the reference this library does not implement are refused, never silently replaced
-  if (opt->BLOWING) return VICGPU_ERR_UNSUPPORTED;
   // QUICK_SOLVE (calc_surf_energy_bal.c:289-309, 400-480; ignored with QUICK_FLUX like in the reference): the reference forces
   // NOFLUX and EXP_TRANS off for the iteration and keeps whatever it last set for the final evaluation -- implemented for
   // runs that have both off; not combined with IMPLICIT
@@ -1543,7 +1558,7 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   o.AERO_RESIST_CANSNOW = opt->AERO_RESIST_CANSNOW; o.SNOW_ALBEDO = opt->SNOW_ALBEDO; o.SNOW_DENSITY = opt->SNOW_DENSITY;
   o.TEMP_TH_TYPE = opt->TEMP_TH_TYPE; o.GLACIER_ID = opt->GLACIER_ID; o.GLACIER_DYNAMICS = opt->GLACIER_DYNAMICS;
   o.frozen_compat = opt->frozen_compat; o.nveg_types = opt->nveg_types; o.wind_h = opt->wind_h; o.CORRPREC = opt->CORRPREC;
-  o.IMPLICIT = opt->IMPLICIT; o.QUICK_SOLVE = (opt->QUICK_SOLVE && !opt->QUICK_FLUX) ? 1 : 0;
+  o.BLOWING = opt->BLOWING ? 1 : 0; o.IMPLICIT = opt->IMPLICIT; o.QUICK_SOLVE = (opt->QUICK_SOLVE && !opt->QUICK_FLUX) ? 1 : 0;
   if (hipSetDevice(device) != hipSuccess) { delete c; return VICGPU_ERR_HIP; }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess
@@ -1667,7 +1682,7 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
   if (c->fd) {
     const int Nn = c->o.Nnode;
     const size_t words = (Nn == 10) ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
-    HIPCHK(c, hipMalloc(&c->d_ctx, sizeof(unsigned long long) * words * (((size_t)nhru + 63) / 64 * 64)));
+    HIPCHK(c, hipMalloc(&c->d_ctx, sizeof(unsigned long long) * ((words + 1) & ~(size_t)1) * (((size_t)nhru + 63) / 64 * 64)));
     HIPCHK(c, hipMalloc(&c->d_pin, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, hipMalloc(&c->d_ts, sizeof(double) * nhru));
     HIPCHK(c, hipMalloc(&c->d_pout, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));

@@ -366,6 +366,8 @@ def make_domain(ncell, opt, ntile=1, tile_classes=None, glacier_top_band=False, 
     d.nslot = nslot
     hpi = np.zeros((C["HPI_NROW"], nhru), dtype=np.int32)
     hpd = np.zeros((C["HPD_NROW"], nhru))
+    # veg_con.sigma_slope / lag_one / fetch (blowing snow only); float32 values like the reference's vegetation file gives
+    hpd[C["HPD_SIGMA_SLOPE"]] = np.float32(0.08); hpd[C["HPD_LAG_ONE"]] = np.float32(0.95); hpd[C["HPD_FETCH"]] = np.float32(1000.0)
     tile_frac = np.full(ntile, (1.0 - bare_fraction) / ntile)
     roots = {0: (0.10, 0.70, 0.20), 1: (0.10, 0.60, 0.30), 2: (0.0, 0.0, 0.0)}
     cells = np.arange(ncell)
