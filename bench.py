@@ -64,6 +64,12 @@ def config(name, compat=False):
         return dict(opt=opt, ncell=CELLS_PER_GPU_CFG4, ntile=5, start_doy=60, glacier=True,
                     workload="cfg4: 125k cells per GPU (1M cells on 8 GPUs), FULL_ENERGY+FROZEN_SOIL (Nnode=10, explicit, %s), "
                              "5 bands x 5 veg tiles, veg slot 0 of the top band = glacier (solve_glacier / surface_fluxes_glac), hourly" % sem)
+    if name == "cfg5":       # BASELINE.json configs[4]: the cfg4 domain as an I/O-overlap stress (run_cfg5)
+        c = config("cfg4", compat)
+        c["workload"] = ("cfg5: one GPU's 125k-cell share of the 1M-cell glacier domain (cfg4), forcing streamed as hourly raw records in "
+                         "chunks, put_data every step, daily output table fetched + gathered every 24 steps inside the timed region, "
+                         "state records at the end")
+        return c
     if name == "cfg2":
         opt = abi.default_options(FULL_ENERGY=1)
         return dict(opt=opt, ncell=10000, ntile=3, start_doy=60,
@@ -176,12 +182,156 @@ def launch_check(args):
     dist.destroy_process_group()
 
 
+RAW_FROM_TABLE = (("VIC_RAW_AIR_TEMP", "VIC_F_AIR_TEMP", 1.0), ("VIC_RAW_PREC", "VIC_F_PREC", 1.0), ("VIC_RAW_PRESSURE_KPA", "VIC_F_PRESSURE", 1e-3),
+                  ("VIC_RAW_VP_KPA", "VIC_F_VP", 1e-3), ("VIC_RAW_SHORTWAVE", "VIC_F_SHORTWAVE", 1.0), ("VIC_RAW_LONGWAVE", "VIC_F_LONGWAVE", 1.0),
+                  ("VIC_RAW_WIND", "VIC_F_WIND", 1.0))
+
+
+def cfg5_sequence(m, f, dmy, step0, nsteps, chunk, out_every, opt, gather, bufs=None):
+    """The cfg5 step sequence on model `m` (vicNl.c:506-610 with the forcing arriving in chunks): steps [step0, step0 + nsteps) of
+    the derived table `f`, handed over as hourly RAW records chunk by chunk (vicgpu_prefetch_forcing_raw: upload + derivation of
+    atmos[rec] on the device while the previous chunk runs), put_data inside every step, and every `out_every` steps the writer's
+    table fetched and passed to `gather`.  Returns the list of gathered tables.  Used by bench.py (timed) and by
+    tests/test_gpu_parity.py::test_cfg5_sequence (checked)."""
+    import numpy as np
+    from vic_amd.abi import C
+    assert nsteps % chunk == 0 and out_every % chunk == 0
+    ncell = f.shape[-1]
+    if bufs is None:
+        bufs = [m.pinned((chunk, C["VIC_NRAW"], opt.dt, ncell)) for _ in range(2)]
+
+    def fill(buf, lo):
+        fs = f[lo:lo + chunk]
+        for name, src, scale in RAW_FROM_TABLE:
+            buf[:, C[name]] = fs[:, C[src], :opt.NF] * scale
+    nch = nsteps // chunk
+    tables = []
+    fill(bufs[0], step0)
+    m.prefetch_forcing_raw(bufs[0], dmy[step0:step0 + chunk]); m.swap_forcing()
+    for k in range(nch):
+        if k + 1 < nch:
+            lo = step0 + (k + 1) * chunk
+            fill(bufs[(k + 1) % 2], lo)                                      # the host prepares the next chunk ...
+            m.prefetch_forcing_raw(bufs[(k + 1) % 2], dmy[lo:lo + chunk])    # ... and starts its upload + derivation
+        m.dist_prec(0, chunk, sync=False)
+        if ((k + 1) * chunk) % out_every == 0:
+            tables.append(gather(m.get_outputs(OUT_VARS, reset=True)))       # one output record leaves the device (waits for its steps)
+        if k + 1 < nch:
+            m.swap_forcing()
+    m.synchronize()
+    return tables
+
+
+def run_cfg5(args, cfg, d, f, sf, dmy, sd0, si0, world, rank, local_rank, use_dist, ncell, ncell_global):
+    """`--config cfg5`: K steps of cfg5_sequence in the timed region, the same K steps with the forcing resident beside it, the
+    upload + derivation of one chunk on its own (how much of it the overlap hides), and the state records at the end."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vic_amd import shard
+    from vic_amd.api import Model
+    opt = cfg["opt"]
+    K, W, CH = args.steps, args.warmup, 6
+    K = max(OUT_STEP_RATIO, (K // OUT_STEP_RATIO) * OUT_STEP_RATIO)             # whole output records
+    W = (W // CH) * CH
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gather_ms = []
+
+    def gather(outs):
+        t0 = time.perf_counter()
+        full = shard.gather_cell_table(outs, [ncell] * world, device=torch.device("cuda", local_rank), root=0) if use_dist else outs
+        gather_ms.append((time.perf_counter() - t0) * 1e3)
+        return full
+
+    def make():
+        m = Model(d, device=local_rank)
+        m.set_state(sd0, si0); m.set_write_fluxes(False); m.put_data_config(OUT_STEP_RATIO); m.put_data_init()
+        return m
+    # resident leg: the same steps with the whole forcing table already in HBM
+    m0 = make()
+    m0.push_forcing(f, sf, dmy); m0.synchronize()
+    if W:
+        m0.dist_prec(0, W, sync=True)
+    barrier(); t0 = time.perf_counter()
+    for k in range(K // OUT_STEP_RATIO):
+        m0.dist_prec(W + k * OUT_STEP_RATIO, OUT_STEP_RATIO, sync=False)
+        m0.get_outputs(OUT_VARS, reset=True)
+    m0.synchronize(); barrier()
+    resident_ms = (time.perf_counter() - t0) / K * 1e3
+    state_ref = m0.get_state()
+    m0.close()
+    # streamed leg (the timed one)
+    m = make()
+    bufs = [m.pinned((CH, C_()["VIC_NRAW"], opt.dt, ncell)) for _ in range(2)]
+    if W:
+        cfg5_sequence(m, f, dmy, 0, W, CH, W, opt, lambda o: o, bufs)
+        m.get_outputs(OUT_VARS, reset=True)
+    m.reset_accum()
+    barrier(); t0 = time.perf_counter()
+    tables = cfg5_sequence(m, f, dmy, W, K, CH, OUT_STEP_RATIO, opt, gather, bufs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, nlaunch = m.last_kernel_ms()
+    same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(m.get_state(), state_ref))
+    nerr = int((m.get_cell_errors() != 0).sum())
+    # one chunk's upload + derivation on its own
+    fs = f[W:W + CH]
+    for name, src, scale in RAW_FROM_TABLE:
+        bufs[0][:, C_()[name]] = fs[:, C_()[src], :opt.NF] * scale
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m.prefetch_forcing_raw(bufs[0], dmy[W:W + CH]); m.swap_forcing(); m.synchronize()
+    upload_ms = (time.perf_counter() - t0) / CH * 1e3
+    # state save: the records in state-file order (write_model_state.c:95-337) to the host
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rec = m.get_state_records()
+    state_save_ms = (time.perf_counter() - t0) * 1e3
+    m.close()
+    streamed_ms = elapsed / K * 1e3
+    hidden = 1.0 - max(0.0, streamed_ms - resident_ms) / upload_ms if upload_ms > 0 else None
+    if rank != 0:
+        return None
+    hru_per_cell = d.nhru // d.ncell
+    balg = b_alg(opt, hru_per_cell)
+    achieved = balg * ncell / (streamed_ms * 1e-3) / 1e9
+    return {
+        "metric": "cell-timesteps/s", "value": world * ncell * K / elapsed, "unit": "cell-timesteps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": streamed_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": cfg["workload"], "cells_per_gpu": ncell, "cells_total": ncell_global, "hru_per_cell": hru_per_cell,
+                   "node_solver": args.node_solver, "forcing_chunk_steps": CH, "out_step_ratio": OUT_STEP_RATIO,
+                   "resident_forcing_ms_per_step": resident_ms, "chunk_upload_and_derive_ms_per_step": upload_ms, "h2d_hidden_frac": hidden,
+                   "output_records_gathered": len(tables), "output_gather_ms": float(np.mean(gather_ms)) if gather_ms else None,
+                   "output_table": "%s as float32 [%d][%d]" % (",".join(OUT_VARS), tables[0].shape[0], tables[0].shape[1]) if tables and tables[0] is not None else None,
+                   "state_save_ms": state_save_ms, "state_record_bytes": int(rec.nbytes), "streamed_state_equals_resident": bool(same),
+                   "cells_with_error_flags": nerr,
+                   "parallelism": "cells sharded across %d GPU(s), output table gathered to rank 0 every %d steps" % (world, OUT_STEP_RATIO)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "whole cfg5 step (pipeline + put_data + streamed forcing)", "kernel_ms_per_launch": streamed_ms,
+                     "algorithmic_bytes_per_cell_step": balg, "csrc_digest": csrc_digest()},
+        "cpu_baseline": {"value": None, "unit": "cell-timesteps/s", "cores": 0, "kind": "port", "sample": "not timed for cfg5 (see the cfg3 line)"},
+    }
+
+
+def C_():
+    from vic_amd.abi import C
+    return C
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--config", default=None, help="cfg3 (default at 1 GPU), cfg4 (default at > 1 GPU), cfg2")
+    ap.add_argument("--config", default=None, help="cfg3 (default at 1 GPU), cfg4 (default at > 1 GPU), cfg2, cfg5 (I/O-overlap stress on the cfg4 domain)")
     ap.add_argument("--compat", action="store_true", help="FROZEN_SOIL as the reference ships it (frozen_soil.c:218-221) instead of 'fixed'")
     ap.add_argument("--node-solver", default="newton", choices=["newton", "brent"],
                     help="frozen-node root finder (vicgpu_options.NODE_SOLVER): converged Newton (default) or the reference's Brent iteration replayed")
@@ -228,6 +378,9 @@ def main():
     opt.NODE_SOLVER = C["VIC_NODE_SOLVER_NEWTON"] if args.node_solver == "newton" else C["VIC_NODE_SOLVER_BRENT"]
     ncell = args.ncell or cfg["ncell"]
     K, W = args.steps, args.warmup
+    if cfg_name == "cfg5":                # whole output records and whole forcing chunks
+        K = args.steps = max(OUT_STEP_RATIO, (K // OUT_STEP_RATIO) * OUT_STEP_RATIO)
+        W = args.warmup = (W // 6) * 6
     # ONE domain of world x ncell cells, cut into contiguous HRU-balanced blocks (shard.partition_cells: every cell has the
     # same number of HRUs here, so the blocks are equal); this rank builds only its block
     ncell_global = ncell * world
@@ -239,6 +392,15 @@ def main():
         # the driver opens the glacier mass-balance accumulation window (accumulateGlacierMassBalance.c:13-67)
         isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
         sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
+    if cfg_name == "cfg5":
+        out = run_cfg5(args, cfg, d, f, sf, dmy, sd0, si0, world, rank, local_rank, use_dist, ncell, ncell_global)
+        if rank == 0:
+            print(json.dumps(out))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     def make_model(dom):
         mm = Model(dom, device=local_rank)
         mm.set_state(sd0, si0)

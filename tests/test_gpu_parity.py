@@ -467,6 +467,79 @@ def test_bench_workload_headline_outputs(name, oracle_lib):
     print(name, "newton vs unmodified oracle, %d free steps: headline state %.2e, accumulated outputs %.2e" % (nsteps, w, worst_acc))
 
 
+def test_cfg5_sequence(oracle_lib):
+    """BASELINE configs[4] as a workload (bench.py --config cfg5 runs exactly this sequence, bench.cfg5_sequence): the glacier +
+    frozen-soil domain, hourly RAW forcing streamed in 6-step chunks with the derivation of atmos[rec] on the device, put_data
+    inside every step, the writer's table fetched every 24 steps, the state in state-file order at the end
+    (vicNl.c:506-610, write_model_state.c:95-337).  Two days: (i) the streamed run equals the run with the whole table resident,
+    bit for bit; (ii) interrupted after day one -- tables and state records handed to a fresh context -- it still does;
+    (iii) the output records and the final state against the oracle running freely on its own derivation of the same records."""
+    import bench
+    from vic_amd.api import Model
+    cfg = bench.config("cfg5")
+    opt = cfg["opt"]
+    d = domain.make_domain(24, opt, ntile=cfg["ntile"], glacier_top_band=True)
+    nsteps, CH, OUT = 48, 6, 24
+    f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=cfg["start_doy"])
+    sd0, si0 = init_state.initial_state(d, f[0])
+    isg = d.hru_iparams[C["HPI_IS_GLACIER"]] != 0
+    sd0[C["SD_GLAC_CUM_MASS_BALANCE"], isg] = 0.0
+    raw = np.zeros((nsteps, C["VIC_NRAW"], opt.dt, d.ncell))
+    for name, src, scale in bench.RAW_FROM_TABLE:
+        raw[:, C[name]] = f[:, C[src], :opt.NF] * scale
+
+    def fresh(sd, si, fx=None, rec=None):
+        m = Model(d); m.set_state(sd, si)
+        if fx is not None:
+            m.set_fluxes(fx); m.set_state_records(rec)
+        m.put_data_config(OUT); m.put_data_init()
+        return m
+    # resident: the whole raw table derived at once, two output records
+    a = fresh(sd0, si0)
+    a.prefetch_forcing_raw(raw, dmy); a.swap_forcing()
+    rec_a = []
+    for k in range(nsteps // OUT):
+        a.dist_prec(k * OUT, OUT)
+        rec_a.append(a.get_outputs(bench.OUT_VARS, reset=True))
+    state_a, records_a = a.get_state(), a.get_state_records()
+    # (i) streamed
+    b = fresh(sd0, si0)
+    rec_b = bench.cfg5_sequence(b, f, dmy, 0, nsteps, CH, OUT, opt, lambda o: o)
+    assert len(rec_b) == 2 and all(np.array_equal(x, y, equal_nan=True) for x, y in zip(rec_a, rec_b))
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(state_a, b.get_state()))
+    assert np.array_equal(records_a, b.get_state_records(), equal_nan=True)
+    # (ii) interrupted after the first output record
+    c1 = fresh(sd0, si0)
+    rec_c = bench.cfg5_sequence(c1, f, dmy, 0, OUT, CH, OUT, opt, lambda o: o)
+    (sd1, si1), fx1, r1 = c1.get_state(), c1.get_fluxes(), c1.get_state_records()
+    c1.close()
+    c2 = fresh(sd1, si1, fx1, r1)
+    rec_c += bench.cfg5_sequence(c2, f, dmy, OUT, nsteps - OUT, CH, OUT, opt, lambda o: o)
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(rec_a, rec_c))
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(state_a, c2.get_state()))
+    assert c2.get_cell_errors().sum() == 0
+    # (iii) the oracle, freely, on its own derivation of the same records
+    orc = oracle_lib.OracleModel(d)
+    fo, so = orc.derive_forcing(raw, 0.0, 1)
+    orc.set_state(sd0, si0)
+    orc.put_data(-1)
+    rec_o = []
+    for s in range(nsteps):
+        fx, co, eo = orc.step(fo[s], so[s], dmy[s])
+        assert eo.sum() == 0
+        orc.put_data(s, fo[s], co, OUT)
+        if (s + 1) % OUT == 0:
+            rec_o.append(np.concatenate([orc.get_output(n, True) for n in bench.OUT_VARS]).astype(np.float32))
+            orc.reset_agg()
+    for k in range(2):
+        w, m = worst(rec_o[k], rec_a[k], "OUT_", floor=1e-3)
+        assert w < FREE_TOL, "output record %d: %s" % (k, m)
+    so_, io_ = orc.get_state()
+    w, m = worst(so_[HEADLINE_STATE_ROWS], state_a[0][HEADLINE_STATE_ROWS], "SD_", floor=1e-4)
+    assert w < FREE_TOL, m
+    assert np.array_equal(io_, state_a[1])
+
+
 def test_bench_workload_full_size_properties():
     """BASELINE size (100k cells x 25 HRUs = 2.5 M HRUs), size-independent properties of the GPU path:
     water balance closes per cell, no cell raises an error flag, and a second run from the same state is bit-identical

@@ -46,8 +46,11 @@ def _worker(rank, world, port, q):
         np.add.at(acc[1], cell, fx[C["FX_BASEFLOW"]] * cv)
     b = shard.partition_cells(d.cell_hru_offset, world)
     full = shard.gather_cell_table(acc, np.diff(b))
+    # the writer's table as bench.py gathers it: float32 rows of ragged shards, to the writer's rank only
+    full32 = shard.gather_cell_table(acc.astype(np.float32), np.diff(b), root=0)
+    assert (full32 is None) == (rank != 0)
     if rank == 0:
-        q.put(full)
+        q.put((full, full32, np.diff(b)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +63,8 @@ def test_two_rank_gloo_matches_single_process(oracle_lib):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    full = q.get(timeout=300)
+    full, full32, ncell_per_rank = q.get(timeout=300)
+    assert ncell_per_rank[0] != ncell_per_rank[1]          # ragged: 23 cells on two ranks
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -83,3 +87,4 @@ def test_two_rank_gloo_matches_single_process(oracle_lib):
         np.add.at(acc[1], cell, fx[C["FX_BASEFLOW"]] * cv)
     assert full.shape == acc.shape
     assert np.array_equal(full, acc)
+    assert full32.dtype == np.float32 and np.array_equal(full32, acc.astype(np.float32))

@@ -1191,6 +1191,13 @@ __global__ __launch_bounds__(256) void vic_state_records(const RArgs a) {
 // A chunk of cells with all their HRUs.  Cells never interact, so every chunk runs the whole step sequence on its own
 // stream, driven by its own host thread: while one chunk is in the thin tail of its Brent rounds (a few stragglers,
 // latency bound) or in a stage kernel (memory / latency bound), the profile solves of the others fill the SIMDs.
+// The host reads the round's list sizes back RB_LAG rounds late (fd_step): it stays that many rounds ahead of the device, so the
+// thin tail rounds -- two short kernels each -- never wait for a host round trip; the price is RB_LAG rounds on empty lists at
+// the end of the iteration (both kernels return at once).
+#ifndef VIC_RB_LAG
+#define VIC_RB_LAG 3
+#endif
+constexpr int RB_LAG = VIC_RB_LAG, RB_DEPTH = RB_LAG + 1;
 struct FdChunk {
   int c0 = 0, ccount = 0;          // cells [c0, c0 + ccount)
   int* d_glist = nullptr;          // their HRUs, ascending
@@ -1199,10 +1206,10 @@ struct FdChunk {
   int *d_fb_list = nullptr, *d_fb_count = nullptr;   // IMPLICIT: HRUs whose Newton iteration failed this round
   int* d_count = nullptr;          // [l * NBUCKET + b] segment sizes of list l, then CNT_CURSOR, CNT_EVALONLY
   int list_cap = 0;                // entries per segment
-  int* h_count = nullptr;          // pinned read-back, two slots of CNT_TOTAL
+  int* h_count = nullptr;          // pinned read-back, RB_DEPTH slots of CNT_TOTAL
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
-  hipEvent_t readback[2] = {nullptr, nullptr};
+  hipEvent_t readback[RB_DEPTH] = {};
   std::string err;
   int status = 0;
   long long rounds = 0, steps = 0;
@@ -1389,7 +1396,8 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
     int nmax = ch->gcount;
-    int pending = -1, pending_list = 0;        // read-back slot issued and not yet looked at, and the list it counts
+    int rb_list[RB_DEPTH];                     // the list each read-back slot counts
+    int rb_first = -1;                         // first round whose counts were read back
     for (int round = 0;; round++) {
       pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur * NBUCKET; pa.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
       pa.evalonly_zero = ch->d_count + CNT_EVALONLY;
@@ -1411,24 +1419,24 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
       CHKCH(ch, hipGetLastError());
       cur ^= 1;
       ch->rounds++;
-      // The list sizes are read back one round late: the copy issued after the previous round sits in the stream ahead of
-      // the kernels just launched, so waiting for it never leaves the GPU idle.  The price is one round on empty lists at
-      // the end (both kernels return at once; the lists and counters stay empty).
-      if (pending >= 0) {
-        CHKCH(ch, hipEventSynchronize(ch->readback[pending]));
-        const int* h = ch->h_count + pending * CNT_TOTAL;
-        int n = 0;
-        for (int b = 0; b < NBUCKET; b++) n += h[pending_list * NBUCKET + b];
-        const int ne = h[CNT_EVALONLY];
-        pending = -1;
-        if (n == 0 && ne == 0) break;
-        nmax = n;
-      }
+      // The list sizes of this round travel to the host behind the kernels just launched; the host looks at the copy issued
+      // RB_LAG rounds ago, which has long arrived, so waiting for it never leaves the GPU idle.  The counts only shrink from
+      // round to round (an HRU either goes on or is through), so a stale count is a valid upper bound for the grid.
       if (round + 2 >= FREE_ROUNDS) {
-        const int slot = round & 1;
+        const int slot = round % RB_DEPTH;
+        if (rb_first < 0) rb_first = round;
         CHKCH(ch, hipMemcpyAsync(ch->h_count + slot * CNT_TOTAL, ch->d_count, sizeof(int) * CNT_TOTAL, hipMemcpyDeviceToHost, st));
         CHKCH(ch, hipEventRecord(ch->readback[slot], st));
-        pending = slot; pending_list = cur;
+        rb_list[slot] = cur;
+      }
+      if (rb_first >= 0 && round - RB_LAG >= rb_first) {
+        const int slot = (round - RB_LAG) % RB_DEPTH;
+        CHKCH(ch, hipEventSynchronize(ch->readback[slot]));
+        const int* h = ch->h_count + slot * CNT_TOTAL;
+        int n = 0;
+        for (int b = 0; b < NBUCKET; b++) n += h[rb_list[slot] * NBUCKET + b];
+        if (n == 0 && h[CNT_EVALONLY] == 0) break;
+        nmax = n;
       }
     }
     ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET;
@@ -1743,7 +1751,7 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
         HIPCHK(c, hipMalloc(&ch.d_fb_list, gb * NBUCKET));
         HIPCHK(c, hipMalloc(&ch.d_fb_count, sizeof(int) * NBUCKET));
       }
-      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * CNT_TOTAL * 2, hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * CNT_TOTAL * RB_DEPTH, hipHostMallocDefault));
       if (ch.gcount) HIPCHK(c, copy_on(c->stream, ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
       HIPCHK(c, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
       HIPCHK(c, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));

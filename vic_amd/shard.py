@@ -59,21 +59,29 @@ def shard_domain(dom, rank, world):
     return sub
 
 
-def gather_cell_table(local, ncell_per_rank, group=None, device=None):
-    """All-gather a per-cell table [nrow][ncell_local] from every rank into [nrow][sum ncell].
+def gather_cell_table(local, ncell_per_rank, group=None, device=None, root=None):
+    """Gather a per-cell table [nrow][ncell_local] from every rank into [nrow][sum ncell].
 
-    `ncell_per_rank` lists every rank's cell count (ragged shards are padded for the collective).  Works on the
-    "nccl" backend (= RCCL on ROCm) with device tensors and on "gloo" with CPU tensors.
+    `ncell_per_rank` lists every rank's cell count (ragged shards are padded for the collective).  root = None: all-gather, every
+    rank gets the table; root = r: gather to the writer's rank only (the others return None and never hold the whole table).
+    Works on the "nccl" backend (= RCCL on ROCm) with device tensors and on "gloo" with CPU tensors.
     """
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     nrow = local.shape[0]
     nmax = int(max(ncell_per_rank))
     src = torch.as_tensor(np.ascontiguousarray(local))          # keeps the table's dtype (float32 writer tables, float64 accumulators)
     t = torch.zeros((nrow, nmax), dtype=src.dtype, device=device)
     t[:, :local.shape[1]] = src.to(t.device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t, group=group)
+    if root is None:
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t, group=group)
+    else:
+        out = [torch.empty_like(t) for _ in range(world)] if rank == root else None
+        dist.gather(t, out, dst=root, group=group)
+        if rank != root:
+            return None
     parts = [o[:, :int(n)].cpu().numpy() for o, n in zip(out, ncell_per_rank)]
     return np.concatenate(parts, axis=1)
