@@ -255,9 +255,14 @@ def run_cfg5(args, cfg, d, f, sf, dmy, sd0, si0, world, rank, local_rank, use_di
         return m
     # resident leg: the same steps with the whole forcing table already in HBM
     m0 = make()
-    m0.push_forcing(f, sf, dmy); m0.synchronize()
+    raw_all = np.zeros((W + K, C_()["VIC_NRAW"], opt.dt, ncell))
+    for name, src, scale in RAW_FROM_TABLE:
+        raw_all[:, C_()[name]] = f[:W + K, C_()[src], :opt.NF] * scale
+    m0.prefetch_forcing_raw(raw_all, dmy[:W + K]); m0.swap_forcing(); m0.synchronize()       # the same records, derived at once
+    del raw_all
     if W:
         m0.dist_prec(0, W, sync=True)
+        m0.get_outputs(OUT_VARS, reset=True)
     barrier(); t0 = time.perf_counter()
     for k in range(K // OUT_STEP_RATIO):
         m0.dist_prec(W + k * OUT_STEP_RATIO, OUT_STEP_RATIO, sync=False)

@@ -40,7 +40,7 @@ extern "C" {
 #define VICGPU_ABI_VERSION 3
 
 #define VIC_NLAYER        3    /* MAX_LAYERS, user_def.h:95 */
-#define VIC_MAX_NODES    18    /* device build limit for options.Nnode (reference MAX_NODES = 50, user_def.h:96) */
+#define VIC_MAX_NODES    24    /* device build limit for options.Nnode (reference MAX_NODES = 50, user_def.h:96) */
 #define VIC_MAX_BANDS    30    /* MAX_BANDS, user_def.h:97 */
 #define VIC_N_PET_TYPES   6    /* vicNl_def.h:213 */
 #define VIC_MAX_ZWTVMOIST 11   /* user_def.h:100 */

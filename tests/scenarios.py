@@ -20,6 +20,7 @@ OPTION_BRANCHES = {
     "frozen_n12": dict(kw=dict(FROZEN, Nnode=12), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=300),
     "frozen_n18": dict(kw=dict(FROZEN, Nnode=18), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=20),
     "frozen_n5": dict(kw=dict(FROZEN, Nnode=5), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=320),
+    "frozen_n24": dict(kw=dict(FROZEN, Nnode=24), variant="fixed", ncell=4, ntile=2, nsteps=80, doy=25),
     # ground heat flux forms (func_surf_energy_bal.c:176-182, 234-276)
     "gf_406": dict(kw=dict(FULL_ENERGY=1, GRND_FLUX_TYPE=C["VIC_GF_406"]), variant="plain", ncell=6, ntile=3, nsteps=200, doy=80),
     "gf_full": dict(kw=dict(FULL_ENERGY=1, GRND_FLUX_TYPE=C["VIC_GF_FULL"]), variant="plain", ncell=6, ntile=3, nsteps=200, doy=80),
@@ -69,6 +70,8 @@ IMPLICIT_BRANCHES = {
     "implicit_exp_trans": dict(kw=dict(FROZEN, IMPLICIT=1, EXP_TRANS=1), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=330),
     "implicit_glacier": dict(kw=dict(FROZEN, IMPLICIT=1, Nband=2), variant="fixed", ncell=4, ntile=2, glacier=True, nsteps=80, doy=100),
     "implicit_noflux_n12": dict(kw=dict(FROZEN, IMPLICIT=1, NOFLUX=1, Nnode=12), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=10),
+    # the implicit solver's own limit (newt_raph_func_fast.c:7: 21 nodes)
+    "implicit_n21": dict(kw=dict(FROZEN, IMPLICIT=1, Nnode=21), variant="fixed", ncell=4, ntile=2, nsteps=80, doy=330),
 }
 
 # QUICK_SOLVE (calc_surf_energy_bal.c:289-309, 400-480): the Tsurf iteration on the nodes above the thaw depth + 4, a second

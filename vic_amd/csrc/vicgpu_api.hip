@@ -1723,12 +1723,12 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
       const int pct = atoi(ev);
       if (pct >= 5 && pct <= 100) c->profile_waves = c->profile_waves * pct / 100 > 0 ? c->profile_waves * pct / 100 : 1;
     }
-    // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  The persistent profile
-    // kernel fills every SIMD, so concurrent chunks mostly queue behind each other; two of them still hide each other's
-    // host round trips and thin tail rounds on a big domain (-3 % step time at 2.5 M HRUs, same-box A/B x3), more do not.
-    // The default stays one chunk: with concurrent chunks the per-kernel durations of a profile overlap and stop adding up
-    // to the step time.
-    int nchunk = 1;
+    // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  Every kernel of the pipeline
+    // is stalled most of its time (dependent fp64 chains in the profile kernel, memory latency in the others: 15 % VALU-active
+    // per wave), so two pipelines side by side fill each other's gaps and thin tail rounds: -6 % step time at 2.5 M HRUs
+    // (27.3 vs 29.0 ms, same-box A/B); three or more lose again.  Default: two chunks for domains of 20k cells or more
+    // (VICGPU_CHUNKS=1 gives per-kernel profiles whose durations add up to the step).
+    int nchunk = (ncell >= 20000) ? 2 : 1;
     if (const char* ev = getenv("VICGPU_CHUNKS")) nchunk = atoi(ev);
     if (nchunk < 1) nchunk = 1;
     if (nchunk > 16) nchunk = 16;
