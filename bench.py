@@ -44,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (non-matrix) peak: 256 CUs x 128 flop/clk x 2.4 GHz
 CELLS_PER_GPU_CFG4 = 125000
 OUT_STEP_RATIO = 24     # hourly steps, daily output records
 # the variables north_star names (runoff, baseflow, SWE, soil moisture [3 layers], glacier mass balance) + evaporation and
@@ -149,6 +150,33 @@ def measured_traffic(config_name, ncell, compat):
     if t.get("csrc_digest") != csrc_digest():
         return None, "committed PMC measurement is stale (device sources changed since %s)" % t.get("round", "?")
     return t.get("hbm_bytes_per_step"), "profiles/%s: %s" % (os.path.basename(path), t.get("method", ""))
+
+
+def valu_roofline(config_name, cell_steps_per_s):
+    """Secondary roofline (the path is bound by divergent fp64 arithmetic, not by HBM): the fp64 operations the
+    reference's algorithm executes per cell-step, counted on the CPU restatement (profiles/flops_<config>.json, written by
+    tools/count_flops.py: adds, multiplies, divisions and square roots counted one each, libm calls listed beside them) times
+    the measured cell-steps/s, against the fp64 vector peak; plus the lanes active per vector instruction from the committed
+    PMC pass (profiles/pmc_<config>.json), when there is one."""
+    path = os.path.join(ROOT, "profiles", "flops_%s.json" % config_name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        fl = json.load(f)
+    ach = fl["fp64_ops_per_cell_step"] * cell_steps_per_s / 1e12
+    out = {"bound": "fp64 VALU", "counted_fp64_ops_per_cell_step": fl["fp64_ops_per_cell_step"], "libm_calls_per_cell_step": fl["libm_calls_per_cell_step"],
+           "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS,
+           "libm_calls_per_s": fl["libm_calls_per_cell_step"] * cell_steps_per_s, "source": "profiles/flops_%s.json (%s)" % (config_name, fl.get("sample", "")),
+           "note": "operations of the REFERENCE's algorithm (its Brent iterations and Gauss-Seidel sweeps); a division, square root or libm call "
+                   "counts as one operation here although it costs ~10-100 vector instructions"}
+    pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % config_name)
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            pj = json.load(f)
+        out["lanes_active_per_valu_inst"] = pj.get("lanes_active_per_valu_inst")
+        out["valu_active_share_of_wave_cycles"] = pj.get("valu_active_share_of_wave_cycles")
+        out["pmc_source"] = "profiles/pmc_%s.json (%s)" % (config_name, pj.get("round", ""))
+    return out
 
 
 def free_port():
@@ -558,6 +586,7 @@ def main():
                          "note": "fp64 VALU / divergence-bound root finding (SURVEY.md 7.3 #4): the algorithmic HBM fraction is small by construction; "
                                  "profiles/ holds the per-kernel rocprofv3 stats and PMC passes"},
         }
+        out["roofline_valu"] = valu_roofline(cfg_name, value / world)       # per GPU
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg)

@@ -148,7 +148,12 @@ constexpr int EBC_W_POST = offsetof(SurfEBConst, delta_t) / 8, EBC_W_ALWAYS = of
               EBC_W_INCL = offsetof(SurfEBConst, lmoist) / 8, EBC_W_EVAP = offsetof(SurfEBConst, Wdew) / 8,
               EBC_W_CANOPY = offsetof(SurfEBConst, Cs2) / 8;
 constexpr int EBM_W_FEED = offsetof(SurfEBMut, deltaCC) / 8, EBM_W_IN3 = offsetof(SurfEBMut, Tsnow_surf) / 8,
-              EBM_W_TSNOW = offsetof(SurfEBMut, ra_used) / 8, EBM_W_RA1 = EBM_W_TSNOW + 1, EBM_W_KEEP = offsetof(SurfEBMut, Tnew2) / 8;
+              EBM_W_TSNOW = offsetof(SurfEBMut, ra_used) / 8, EBM_W_RA1 = EBM_W_TSNOW + 1, EBM_W_VV = offsetof(SurfEBMut, vv) / 8,
+              EBM_W_KEEP = offsetof(SurfEBMut, Tnew2) / 8;
+static_assert(offsetof(SurfEBMut, fusion) / 8 == EBM_W_IN3 - 1 && offsetof(SurfEBMut, layerevap) / 8 == EBM_W_VV + 3, "SurfEBMut layout");
+#ifndef VIC_FINAL_SHORTCUT
+#define VIC_FINAL_SHORTCUT 1
+#endif
 constexpr size_t CW_SV = sizeof(SurfSolve) / 8, CW_EBM = sizeof(SurfEBMut) / 8, CW_EBC = EBC_W_CANOPY,      // Cs2 is never parked
                  CW_P = sizeof(SubStep) / 8, CW_L = sizeof(SubLoop) / 8, CW_C = sizeof(StepConst) / 8;
 constexpr size_t CO_SV = 0, CO_EBM = CO_SV + CW_SV, CO_EBC = CO_EBM + CW_EBM, CO_P = CO_EBC + CW_EBC, CO_L = CO_P + CW_P,
@@ -857,7 +862,10 @@ struct EArgs {
   int month;
 };
 
-__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const EArgs a) {
+#ifndef VIC_EVAL_WAVES
+#define VIC_EVAL_WAVES 2
+#endif
+__global__ __launch_bounds__(64) VIC_WAVES_PER_EU(VIC_EVAL_WAVES, VIC_EVAL_WAVES) void vic_surf_eval(const EArgs a) {
   const int gi = blockIdx.x * 64 + threadIdx.x;
   if (gi == 0) *a.profile_next = 0;
   if (gi >= a.gcount) return;
@@ -900,7 +908,23 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   const double fx = ok ? eb.eval(a.o, s3, sv.x, po[1], po[2]) : ERROR_VAL;
   const bool was_quick = sv.stage == SurfSolve::ROOT_QUICK;
   const int stage_before = sv.stage;
+  const double x_eval = sv.x;
   surf_solve_consume(a.o, sv, eb, eb, fx);
+  // The iteration has just ended on the point it has just evaluated (the usual end of a Brent iteration: the newest point is
+  // the best one): the evaluation "at the root" the reference makes next (calc_surf_energy_bal.c:489-506) would repeat this
+  // one -- same trial temperature, same profile record, and for an HRU without a thin snowpack nothing an evaluation leaves
+  // behind feeds the next -- so it is booked as done here instead of in another round.  Not taken: thin snowpack (the vapour
+  // fluxes are carried from call to call), fallback / error results, QUICK_SOLVE and IMPLICIT (their final evaluation solves
+  // another column / is always solved again).
+  bool at_root = false;
+#if VIC_FINAL_SHORTCUT
+  if (stage_before == SurfSolve::ROOT && sv.stage == SurfSolve::FINAL && !a.implicit && !a.o.QUICK_SOLVE && !(cls & EBG_INCL) && sv.ok
+      && sv.fbflag == 0 && sv.Tsurf == x_eval && fabs(fx) < 1.e30) {
+    sv.final_slot = slot;
+    surf_solve_consume(a.o, sv, eb, eb, fx);       // FINAL -> DONE with this evaluation's residual
+    at_root = true;
+  }
+#endif
   if (was_quick && sv.stage != SurfSolve::ROOT_QUICK) {
     // QUICK_SOLVE: from here on the whole column is solved; the records of the shortened column are not its solutions
     a.jl[g] = a.Nn - 1;
@@ -919,8 +943,18 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(2, 2) void vic_surf_eval(const
   // flags, stage, record bookkeeping) is written when it does
   if (sv.stage == stage_before && (sv.stage == SurfSolve::ROOT || sv.stage == SurfSolve::ROOT_QUICK)) ctx_put_words(cx, CO_SV, sv, 0, (int)CW_SV_ITER);
   else ctx_put(cx, CO_SV, sv);
-  if (sv.stage == SurfSolve::DONE) ctx_put(cx, CO_EBM, static_cast<const SurfEBMut&>(eb));
-  else if (cls & EBG_INCL) ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, EBM_W_FEED);
+  if (sv.stage == SurfSolve::DONE) {
+    const SurfEBMut& m = eb;
+    if (at_root) {
+      // an evaluation of the iteration has not fetched the inputs it only passes through: written back are the outputs and
+      // what this HRU's branch of the evaluation assigns (vic_surface.hpp); the rest keeps the values the set-up parked
+      ctx_put_words(cx, CO_EBM, m, EBM_W_KEEP, (int)CW_EBM);
+      ctx_put_words(cx, CO_EBM, m, EBM_W_TSNOW, EBM_W_TSNOW + 1);                                   // ra_used[0]
+      if (cls & EBG_FROZEN) ctx_put_words(cx, CO_EBM, m, EBM_W_IN3 - 1, EBM_W_IN3);                 // fusion
+      if (cls & EBG_CANOPY) ctx_put_words(cx, CO_EBM, m, EBM_W_VV, EBM_W_VV + 6);                   // vv, layerevap[3]
+      else if (cls & EBG_EVAP) ctx_put_words(cx, CO_EBM, m, EBM_W_VV + 3, EBM_W_VV + 4);            // layerevap[0] (arno_evap)
+    } else ctx_put(cx, CO_EBM, m);
+  } else if (cls & EBG_INCL) ctx_put_words(cx, CO_EBM, static_cast<const SurfEBMut&>(eb), 0, EBM_W_FEED);
   if (sv.stage == SurfSolve::DONE) a.hstate[g] = 2;
   else if (need_solve) { a.ts[g] = sv.x; a.pslot[g] = slot ^ 1; }     // keep the record just used, overwrite the older one
   list_append(a.list_next, a.count_next, a.list_cap, need_solve, a.hkey[g], g);
