@@ -583,9 +583,12 @@ double orc_calc_surf_energy_bal(const orc_model *m, double Le, double LongUnderI
     if (INCLUDE_SNOW) { T_lower = energy->T[0] - ORC_SURF_DT; T_upper = 0.; }
     else { T_lower = 0.5 * (energy->T[0] + Tair) - ORC_SURF_DT; T_upper = 0.5 * (energy->T[0] + Tair) + ORC_SURF_DT; }
     if (m->opt.QUICK_SOLVE && !m->opt.QUICK_FLUX) {
-      /* calc_surf_energy_bal.c:289-299: iterate on the nodes down to the thaw depth + 4 only (NOFLUX / EXP_TRANS are forced
-       * FALSE there, :298-309: this restatement is for runs that have them off anyway, vicgpu_create refuses the others) */
+      /* calc_surf_energy_bal.c:289-309: iterate on the nodes down to the thaw depth + 4 only, with NOFLUX and EXP_TRANS forced
+       * FALSE -- the local copies the final evaluation sees too: NOFLUX comes back only with a second iteration (:403),
+       * EXP_TRANS never does on this branch (the linear-spacing coefficients then run on whatever node geometry the run has) */
       int tmpNnodes = 0;
+      c.NOFLUX = 0;
+      c.EXP_TRANS = 0;
       for (nidx = Nnodes - 5; nidx >= 0; nidx--)
         if (energy->T[nidx] >= 0 && energy->T[nidx + 1] < 0) tmpNnodes = nidx + 1;
       if (tmpNnodes == 0) {
@@ -601,6 +604,7 @@ double orc_calc_surf_energy_bal(const orc_model *m, double Le, double LongUnderI
     }
     if (Ts_old * Tsurf < 0 && m->opt.QUICK_SOLVE) {                                   /* :400-480: again on the whole column */
       c.Nnodes = Nnodes;
+      c.NOFLUX = m->opt.NOFLUX;                                                       /* :403 */
       c.Tsnow_surf = snow->surf_temp;              /* a fresh SurfEnergyBal object: by-value members restart */
       Tsurf = orc_root_brent(T_lower, T_upper, orc_surf_energy_bal, &c);
       if (orc_is_error(Tsurf)) {

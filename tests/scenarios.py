@@ -80,6 +80,12 @@ QUICK_SOLVE_BRANCHES = {
     "quick_solve": dict(kw=dict(FROZEN, QUICK_SOLVE=1), variant="fixed", ncell=4, ntile=3, nsteps=150, doy=95),
     "quick_solve_winter": dict(kw=dict(FROZEN, QUICK_SOLVE=1, Nnode=12), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=330),
     "quick_solve_glacier": dict(kw=dict(FROZEN, QUICK_SOLVE=1, Nband=2), variant="fixed", ncell=4, ntile=2, glacier=True, nsteps=80, doy=100),
+    # with NOFLUX / EXP_TRANS: the iteration runs with both forced off, NOFLUX returns with the second iteration only, EXP_TRANS
+    # not at all (calc_surf_energy_bal.c:298-309, 403)
+    "quick_solve_noflux": dict(kw=dict(FROZEN, QUICK_SOLVE=1, NOFLUX=1), variant="fixed", ncell=4, ntile=3, nsteps=150, doy=95),
+    "quick_solve_exp_trans": dict(kw=dict(FROZEN, QUICK_SOLVE=1, EXP_TRANS=1), variant="fixed", ncell=4, ntile=2, nsteps=100, doy=95),
+    "quick_solve_noflux_exp_trans_n12": dict(kw=dict(FROZEN, QUICK_SOLVE=1, NOFLUX=1, EXP_TRANS=1, Nnode=12), variant="fixed", ncell=4, ntile=2,
+                                             nsteps=100, doy=330),
 }
 
 

@@ -37,6 +37,13 @@ def needs_build():
 # register budget is part of their design must not spill behind one's back -- a few hundred bytes of scratch in the evaluation
 # kernel cost 5 ms per step twice this round.  Limits are per kernel name prefix: (max VGPRs, max scratch bytes).
 RESOURCE_LIMITS = {
+    # the 512-register kernels (one wave per SIMD, spills into AGPRs and scratch by design): ceilings a little above today's
+    # figures, so that a change that inflates them -- the state in which round 2 saw hipcc produce wrong code -- stops the build
+    "vic_hru_step<3, false>": (256, 3200),
+    "vic_hru_step<3, true>": (256, 1800),
+    "vic_hru_step<10, true>": (256, 2200),
+    "vic_fd_stage<10, true, false>": (256, 800),
+    "vic_fd_stage<10, false, false>": (256, 600),
     "vic_surf_eval": (256, 0),
     "vic::vic_profile_solve_reg<10": (256, 128),
     "vic::vic_profile_solve_lockstep": (256, 0),

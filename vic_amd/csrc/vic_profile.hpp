@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
       int cadd[NN];
 #pragma unroll
       for (int k = 0; k < NN; k++) T0v[k] = T0(k);
-      profile_finish<NN>(a.jl ? jl_lane + 1 : Nn, a.TFALLBACK != 0, converged, ok, fbmask, T, T0v, cadd);
+      profile_finish<NN>(a.jl ? (jl_lane + 1 < Nn ? jl_lane + 1 : Nn) : Nn, a.TFALLBACK != 0, converged, ok, fbmask, T, T0v, cadd);
       double* __restrict__ rec = a.pout + (size_t)hru * pout_hru_stride(Nn) + ps * pout_stride(Nn);
       int* __restrict__ cnt = reinterpret_cast<int*>(rec + Nn + 1);
 #pragma unroll
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
       }
     }
     if (have && !sweeping) {                        // this lane's item is through: finish it and free the lane
-      const int nq = a.jl ? jl_lane + 1 : Nn;      // the column this solve covered (QUICK_SOLVE: shorter)
+      const int nq = a.jl ? (jl_lane + 1 < Nn ? jl_lane + 1 : Nn) : Nn;      // the column this solve covered (QUICK_SOLVE: shorter)
       if (ok && a.TFALLBACK) {      // cold-nose hack, frozen_soil.c:470-484 (sic: Tlast[j+1] - T(j)); Tlast == T0
 #pragma unroll 1
         for (int k = 1; k < nq - 1; k++) {

@@ -54,8 +54,35 @@ static hipError_t fill_on(hipStream_t st, void* dst, int value, size_t bytes) {
   return e;
 }
 
+// hstate[hru]: bits 0-1 state (0 idle, 1 evaluation pending, 2 root found: the stage kernel's turn), from bit 2 the EBG_* class
+// of the root find.  (Stage, profile record and forcing sub-step packed into the same word, so that every load of the
+// evaluation kernel can issue behind this one, were measured: 26.9 / 27.2 vs 27.0 / 27.2 ms per step -- nothing; removed.)
+constexpr int HS_STATE = 3, HS_CLS_SHIFT = 2;
+// XCD-aware launch order.  HRUs are numbered slot-major (hru = slot * ncell + cell), so the 64 HRUs of a block are 64
+// consecutive cells of one (tile, band) slot, and the ~300 cell-parameter rows and the forcing rows of those cells are read
+// again by the block of every other slot.  Workgroups go round-robin over the 8 XCDs and every XCD has its own L2: in launch
+// order "all cells of slot 0, then slot 1 ..." those re-reads are a whole domain apart and come from HBM every time.  With
+// map_nslot > 0 a launch covers a REGULAR list (nslot slots x ccount cells, entry = slot * ccount + cell) and block b takes
+// cell block (b >> 3) / nslot * 8 + (b & 7) of slot (b >> 3) % nslot: the blocks of one cell block's slots are consecutive on
+// ONE XCD, so its table rows are fetched from HBM once and hit in that XCD's L2 for the other slots.
+struct LaunchMap {
+  int nslot = 0, ccount = 0;         // nslot == 0: identity (irregular lists)
+  __host__ __device__ int nblocks(int gcount) const {
+    if (nslot == 0) return (gcount + 63) / 64;
+    const int ncb = (ccount + 63) / 64;
+    return (ncb + 7) / 8 * 8 * nslot;
+  }
+  // list index of (block, lane), or -1
+  VIC_DEV int index(int block, int lane, int gcount) const {
+    if (nslot == 0) { const int gi = block * 64 + lane; return gi < gcount ? gi : -1; }
+    const int q = block >> 3, cb = q / nslot * 8 + (block & 7), cell = cb * 64 + lane;
+    return cell < ccount ? (q % nslot) * ccount + cell : -1;
+  }
+};
+
 struct KArgs {
   Opt o;
+  LaunchMap map;
   int ncell, nhru, nveg_rows, write_fluxes;
   const double* veglib;
   const double* cell_params;
@@ -603,8 +630,8 @@ VIC_DEV void hru_epilogue(const KArgs& a, int g, const CellView& cv, const Soil3
 // The whole HRU step in one lane: glacier HRUs (GLAC) and QUICK_FLUX (no soil-profile solve)
 template <int NN, bool GLAC>
 __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
-  const int gi = blockIdx.x * 64 + threadIdx.x;
-  if (gi >= a.gcount) return;
+  const int gi = a.map.index(blockIdx.x, threadIdx.x, a.gcount);
+  if (gi < 0) return;
   const int g = a.glist ? a.glist[gi] : gi;
   const Opt& o = a.o;
   const HruId id = hru_id(a, g);
@@ -664,14 +691,14 @@ __global__ __launch_bounds__(64) void vic_hru_step(const KArgs a) {
 // another sub-step and that code is not instantiated).
 template <int NN, bool FIRST, bool MULTI>
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const KArgs a) {
-  const int gi = blockIdx.x * 64 + threadIdx.x;
-  if (gi >= a.gcount) return;
+  const int gi = a.map.index(blockIdx.x, threadIdx.x, a.gcount);
+  if (gi < 0) return;
   const int g = a.glist ? a.glist[gi] : gi;
   const Opt& o = a.o;
   const HruId id = hru_id(a, g);
   if (id.run && id.is_glacier) return;              // vic_hru_step<NN, true> owns glacier HRUs
   if (FIRST && !id.run) { store_zero_record(a, g); a.hstate[g] = 0; return; }
-  if (!FIRST && (a.hstate[g] & 3) != 2) return;
+  if (!FIRST && (a.hstate[g] & HS_STATE) != 2) return;
   CellView cv{a.cell_params, a.ncell, id.c, o.Nnode, o.Nband};
   VegLib vl{a.veglib};
   Forcing fc{a.forcing, a.snowflag, a.ncell, id.c, o.NR + 1};
@@ -813,11 +840,13 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
           if (n <= Nn - 5 && w.nd.T[n] >= 0 && w.nd.T[(n + 1 < NN) ? n + 1 : n] < 0) tmpNnodes = n + 1;
         if (tmpNnodes == 0) tmpNnodes = (w.nd.T[0] <= 0 && w.nd.T[1] >= 0) ? Nn : 3;
         else tmpNnodes += 4;
-        a.jl[g] = ((sv.stage == SurfSolve::ROOT_QUICK) ? tmpNnodes : Nn) - 1;
+        // (the iteration runs with NOFLUX forced off, calc_surf_energy_bal.c:298; without an iteration -- no FULL_ENERGY -- the
+        // run's own NOFLUX decides whether the bottom node is solved)
+        a.jl[g] = (sv.stage == SurfSolve::ROOT_QUICK) ? tmpNnodes - 1 : (o.NOFLUX ? Nn : Nn - 1);
       }
       a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 0)] = NAN;      // no solve on record yet
       a.pout[(size_t)g * pout_hru_stride(Nn) + pout_key(Nn, 1)] = NAN;
-      a.hstate[g] = 1 | (cls << 2);
+      a.hstate[g] = 1 | (cls << HS_CLS_SHIFT);
       pend = true;
       PROF_ADD(14, t_put);
     }
@@ -838,6 +867,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(1, 1) void vic_fd_stage(const 
 // temperature whose soil profile has just been solved, then one step of the Brent iteration on Tsurf.
 struct EArgs {
   Opt o;
+  LaunchMap map;
   int ncell, nhru, Nn;
   const int* glist;
   int gcount;
@@ -856,6 +886,13 @@ struct EArgs {
   const int* hkey;
   int* profile_next;     // work-list cursor of the profile kernel, cleared for its next launch
   int* evalonly;         // HRUs that wait for an evaluation without a solve (final evaluation on record)
+  int* eo_list_next;     // ... and which: with the work list this is every HRU the round leaves pending
+  // sparse rounds (null in the dense ones, which go through glist / map and test hstate): lane = pending HRU, taken from the
+  // work list the profile kernel has just gone through and from the evaluation-only list of the round before
+  const int* list_cur;
+  const int* count_cur;  // [NBUCKET]
+  const int* eo_list_cur;
+  const int* eo_count_cur;
   int implicit;          // IMPLICIT: the final evaluation is always solved again (its fallback flags depend on the solves before it)
   const double* veglib;  // for the table-derived part of the residual's inputs (surf_cell_fill)
   const double* forcing; // this step
@@ -866,15 +903,41 @@ struct EArgs {
 #define VIC_EVAL_WAVES 2
 #endif
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(VIC_EVAL_WAVES, VIC_EVAL_WAVES) void vic_surf_eval(const EArgs a) {
-  const int gi = blockIdx.x * 64 + threadIdx.x;
-  if (gi == 0) *a.profile_next = 0;
-  if (gi >= a.gcount) return;
-  const int g = a.glist ? a.glist[gi] : gi;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.profile_next = 0;
+  int g;
+  if (a.list_cur) {
+    // Sparse round: one lane per pending HRU.  A dense launch pays a whole wave -- its chain of dependent loads -- for every
+    // 64 HRUs of which one is pending; from the round in which few are, the waves are formed from the lists instead.
+    __shared__ int bcount[NBUCKET];
+    for (int b = threadIdx.x; b < NBUCKET; b += 64) bcount[b] = a.count_cur[b];
+    __syncthreads();
+    int nsolve = 0;
+#pragma unroll 1
+    for (int b = 0; b < NBUCKET; b++) nsolve += bcount[b];
+    const int gi = blockIdx.x * 64 + threadIdx.x;
+    if (gi >= nsolve + *a.eo_count_cur) return;
+    if (gi < nsolve) {
+      int rem = gi, found = 0;
+#pragma unroll 1
+      for (int b = 0; b < NBUCKET; b++) {
+        const int cb = bcount[b];
+        if (rem < cb) { found = b * a.list_cap + rem; break; }
+        rem -= cb;
+      }
+      g = a.list_cur[found];
+    } else g = a.eo_list_cur[gi - nsolve];
+  } else {
+    const int gi = a.map.index(blockIdx.x, threadIdx.x, a.gcount);
+    if (gi < 0) return;
+    g = a.glist ? a.glist[gi] : gi;
+  }
   const int hs = a.hstate[g];
-  if ((hs & 3) != 1) return;
-  const int cls = hs >> 2;
+  if ((hs & HS_STATE) != 1) return;
+  const int cls = hs >> HS_CLS_SHIFT;
   const size_t nh = a.nhru;
   const int c = a.hpi[(size_t)HPI_CELL * nh + g];
+  const int veg_idx = a.hpi[(size_t)HPI_VEG_INDEX * nh + g];
+  const int ps = a.pslot[g];
   CellView cv{a.cell_params, a.ncell, c, a.o.Nnode, a.o.Nband};
   const Soil3 s3 = load_soil3(cv);
   SurfSolve sv;
@@ -882,11 +945,14 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(VIC_EVAL_WAVES, VIC_EVAL_WAVES
   const CtxRef cx = CtxRef::at(a.ctx, a.ctx_words, g);
   ctx_get(cx, CO_SV, sv);
   ebc_get(cx, eb, cls);
+  const bool is_final = sv.stage == SurfSolve::FINAL;
+  // the record the profile kernel has just written, or the one found on record for the final evaluation
+  const int slot = sv.on_record ? sv.final_slot : ps;
   {
     // of SurfEBMut an evaluation of the iteration reads what it cannot know otherwise; the final one reads every input, since
     // what it does not assign passes through to the bookkeeping (vic_surface.hpp)
     SurfEBMut& m = eb;
-    if (sv.stage == SurfSolve::FINAL) ctx_get_words(cx, CO_EBM, m, 0, EBM_W_KEEP);
+    if (is_final) ctx_get_words(cx, CO_EBM, m, 0, EBM_W_KEEP);
     else {
       if (cls & EBG_INCL) ctx_get_words(cx, CO_EBM, m, 0, EBM_W_FEED);
       ctx_get_words(cx, CO_EBM, m, EBM_W_FEED, EBM_W_IN3);
@@ -897,11 +963,9 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(VIC_EVAL_WAVES, VIC_EVAL_WAVES
   {
     const VegLib vl{a.veglib};
     const Forcing fc{a.forcing, nullptr, a.ncell, c, a.o.NR + 1};
-    surf_cell_fill(eb, cv, vl, s3, fc, eb.hidx, a.hpi[(size_t)HPI_VEG_INDEX * nh + g], a.month);
+    surf_cell_fill(eb, cv, vl, s3, fc, eb.hidx, veg_idx, a.month);
   }
   const double* __restrict__ rec = a.pout + (size_t)g * pout_hru_stride(a.Nn);
-  // the record the profile kernel has just written, or the one found on record for the final evaluation
-  const int slot = sv.on_record ? sv.final_slot : a.pslot[g];
   const double* __restrict__ po = rec + slot * pout_stride(a.Nn);
   const bool ok = (((unsigned long long)__double_as_longlong(po[a.Nn])) >> 32) & 1ull;
   if (sv.stage == SurfSolve::FINAL) sv.final_slot = slot;
@@ -926,8 +990,9 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(VIC_EVAL_WAVES, VIC_EVAL_WAVES
   }
 #endif
   if (was_quick && sv.stage != SurfSolve::ROOT_QUICK) {
-    // QUICK_SOLVE: from here on the whole column is solved; the records of the shortened column are not its solutions
-    a.jl[g] = a.Nn - 1;
+    // QUICK_SOLVE: from here on the whole column is solved; the records of the shortened column are not its solutions.  NOFLUX
+    // comes back with a second iteration only (calc_surf_energy_bal.c:403); the final evaluation keeps what was last set
+    a.jl[g] = (sv.stage == SurfSolve::ROOT && a.o.NOFLUX) ? a.Nn : a.Nn - 1;
     a.pout[(size_t)g * pout_hru_stride(a.Nn) + pout_key(a.Nn, 0)] = NAN;
     a.pout[(size_t)g * pout_hru_stride(a.Nn) + pout_key(a.Nn, 1)] = NAN;
   }
@@ -959,8 +1024,15 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(VIC_EVAL_WAVES, VIC_EVAL_WAVES
   else if (need_solve) { a.ts[g] = sv.x; a.pslot[g] = slot ^ 1; }     // keep the record just used, overwrite the older one
   list_append(a.list_next, a.count_next, a.list_cap, need_solve, a.hkey[g], g);
   {
-    const unsigned long long m = __ballot(sv.stage != SurfSolve::DONE && !need_solve);
-    if (m != 0 && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(a.evalonly, __popcll(m));
+    const bool eo = sv.stage != SurfSolve::DONE && !need_solve;
+    const unsigned long long m = __ballot(eo);
+    if (m != 0) {
+      const int lane = (int)__lane_id(), lead = __ffsll((long long)m) - 1;
+      int base = 0;
+      if (lane == lead) base = atomicAdd(a.evalonly, __popcll(m));
+      base = __shfl(base, lead);
+      if (eo) a.eo_list_next[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+    }
   }
 }
 
@@ -1236,9 +1308,11 @@ struct FdChunk {
   int c0 = 0, ccount = 0;          // cells [c0, c0 + ccount)
   int* d_glist = nullptr;          // their HRUs, ascending
   int gcount = 0;
+  LaunchMap map;                   // XCD-aware launch order when the chunk's list is regular (slot-major, every slot ccount cells)
   int* d_list[2] = {nullptr, nullptr};   // work lists (HRU ids)
   int *d_fb_list = nullptr, *d_fb_count = nullptr;   // IMPLICIT: HRUs whose Newton iteration failed this round
-  int* d_count = nullptr;          // [l * NBUCKET + b] segment sizes of list l, then CNT_CURSOR, CNT_EVALONLY
+  int* d_count = nullptr;          // [l * NBUCKET + b] segment sizes of list l, then CNT_CURSOR, CNT_EVALONLY + l
+  int* d_elist[2] = {nullptr, nullptr};  // evaluation-only lists (flat, gcount entries): pending HRUs that need no solve
   int list_cap = 0;                // entries per segment
   int* h_count = nullptr;          // pinned read-back, RB_DEPTH slots of CNT_TOTAL
   hipStream_t stream = nullptr;
@@ -1290,6 +1364,7 @@ struct vicgpu_ctx {
   int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr, *d_lastexp = nullptr, *d_jl = nullptr;
   double* d_pimp = nullptr;        // IMPLICIT only
   int profile_waves = 0;           // resident waves of the profile kernel
+  int eval_list_pct = 25;          // the evaluation kernel runs from the pending list once at most this share of the HRUs is pending
   bool node_newton = false;        // frozen-node root finder: safeguarded Newton instead of the reference's Brent iteration
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
@@ -1312,6 +1387,7 @@ static void free_domain(vicgpu_ctx* c) {
   c->put_on = false;
   for (FdChunk& ch : c->chunks) {
     HIPIGN(hipFree(ch.d_glist)); HIPIGN(hipFree(ch.d_list[0])); HIPIGN(hipFree(ch.d_list[1])); HIPIGN(hipFree(ch.d_count));
+    HIPIGN(hipFree(ch.d_elist[0])); HIPIGN(hipFree(ch.d_elist[1]));
     HIPIGN(hipFree(ch.d_fb_list)); HIPIGN(hipFree(ch.d_fb_count));
     if (ch.h_count) HIPIGN(hipHostFree(ch.h_count));
     if (ch.done) HIPIGN(hipEventDestroy(ch.done));
@@ -1331,7 +1407,7 @@ static void free_domain(vicgpu_ctx* c) {
 
 template <int NN>
 static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool ordinary, bool glacier) {
-  const int nblk = (ka.gcount + 63) / 64;
+  const int nblk = ka.map.nblocks(ka.gcount);
   // ordinary HRUs run the monolithic kernel with QUICK_FLUX only (Nnode == 3); the other node counts never instantiate it
   if constexpr (NN == 3) {
     if (ordinary) hipLaunchKernelGGL((vic_hru_step<NN, false>), dim3(nblk), dim3(64), 0, st, ka);
@@ -1342,7 +1418,7 @@ static hipError_t launch_hru(const KArgs& ka, hipStream_t st, bool ordinary, boo
 
 template <int NN>
 static hipError_t launch_fd_stage(const KArgs& ka, bool multi, hipStream_t st) {
-  const dim3 grid((ka.gcount + 63) / 64), block(64);
+  const dim3 grid(ka.map.nblocks(ka.gcount)), block(64);
   if (ka.phase == 0) {
     if (multi) hipLaunchKernelGGL((vic_fd_stage<NN, true, true>), grid, block, 0, st, ka);
     else hipLaunchKernelGGL((vic_fd_stage<NN, true, false>), grid, block, 0, st, ka);
@@ -1392,7 +1468,7 @@ static int profile_resident_waves(int device, bool newton) {
     }                                                                                                  \
   } while (0)
 
-constexpr int CNT_CURSOR = 2 * NBUCKET, CNT_EVALONLY = 2 * NBUCKET + 1, CNT_TOTAL = 2 * NBUCKET + 2;
+constexpr int CNT_CURSOR = 2 * NBUCKET, CNT_EVALONLY = 2 * NBUCKET + 1, CNT_TOTAL = 2 * NBUCKET + 3;    // CNT_EVALONLY + l: of list l
 
 // One model step of the finite-difference pipeline for one chunk (see the header of this file).  Blocks the calling
 // host thread: the number of Brent rounds is data dependent, so the pending count is read back once the first rounds
@@ -1403,7 +1479,7 @@ static int fd_read_count(FdChunk* ch, int which, int* nsolve, int* nevalonly) {
   int n = 0;
   for (int b = 0; b < NBUCKET; b++) n += ch->h_count[which * NBUCKET + b];
   *nsolve = n;
-  *nevalonly = ch->h_count[CNT_EVALONLY];
+  *nevalonly = ch->h_count[CNT_EVALONLY + which];
   return VICGPU_OK;
 }
 
@@ -1420,21 +1496,22 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.pslot = c->d_pslot; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
   pa.TFALLBACK = c->o.TFALLBACK; pa.next = ch->d_count + CNT_CURSOR; pa.cap = ch->list_cap; pa.jl = c->d_jl;
   EArgs ea;
-  ea.o = c->o; ea.ncell = c->ncell; ea.nhru = c->nhru; ea.Nn = Nn; ea.glist = ch->d_glist; ea.gcount = ch->gcount;
+  ea.o = c->o; ea.ncell = c->ncell; ea.nhru = c->nhru; ea.Nn = Nn; ea.glist = ch->d_glist; ea.gcount = ch->gcount; ea.map = ch->map;
   ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
   ea.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
-  ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + CNT_CURSOR; ea.evalonly = ch->d_count + CNT_EVALONLY;
+  ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + CNT_CURSOR;
   ea.list_cap = ch->list_cap; ea.hkey = c->d_hkey; ea.implicit = c->o.IMPLICIT; ea.jl = c->d_jl;
   ea.veglib = c->d_veglib; ea.forcing = ka.forcing; ea.month = ka.dmy.month;
   const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
     int nmax = ch->gcount;
+    int npend = -1;                            // upper bound of the evaluations pending (solves + on-record finals), once known
     int rb_list[RB_DEPTH];                     // the list each read-back slot counts
     int rb_first = -1;                         // first round whose counts were read back
     for (int round = 0;; round++) {
       pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur * NBUCKET; pa.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
-      pa.evalonly_zero = ch->d_count + CNT_EVALONLY;
+      pa.evalonly_zero = ch->d_count + CNT_EVALONLY + (cur ^ 1);
       if (c->o.IMPLICIT) {
         // the Newton iteration for every listed HRU; those it fails for go on the fall-back list, which the explicit kernel
         // (the same one, on that list) solves right after (func_surf_energy_bal.c:192-222)
@@ -1449,7 +1526,15 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
       CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, c->node_newton, st)
                      : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, c->node_newton, st)));
       ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1) * NBUCKET;
-      hipLaunchKernelGGL(vic_surf_eval, dim3((ch->gcount + 63) / 64), dim3(64), 0, st, ea);
+      ea.evalonly = ch->d_count + CNT_EVALONLY + (cur ^ 1); ea.eo_list_next = ch->d_elist[cur ^ 1];
+      if (npend >= 0 && (long long)npend * 100 <= (long long)ch->gcount * c->eval_list_pct) {
+        ea.list_cur = ch->d_list[cur]; ea.count_cur = ch->d_count + cur * NBUCKET;
+        ea.eo_list_cur = ch->d_elist[cur]; ea.eo_count_cur = ch->d_count + CNT_EVALONLY + cur;
+        hipLaunchKernelGGL(vic_surf_eval, dim3((npend + 63) / 64 > 0 ? (npend + 63) / 64 : 1), dim3(64), 0, st, ea);
+      } else {
+        ea.list_cur = ea.count_cur = ea.eo_list_cur = ea.eo_count_cur = nullptr;
+        hipLaunchKernelGGL(vic_surf_eval, dim3(ea.map.nblocks(ch->gcount)), dim3(64), 0, st, ea);
+      }
       CHKCH(ch, hipGetLastError());
       cur ^= 1;
       ch->rounds++;
@@ -1469,8 +1554,10 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
         const int* h = ch->h_count + slot * CNT_TOTAL;
         int n = 0;
         for (int b = 0; b < NBUCKET; b++) n += h[rb_list[slot] * NBUCKET + b];
-        if (n == 0 && h[CNT_EVALONLY] == 0) break;
+        const int neo = h[CNT_EVALONLY + rb_list[slot]];
+        if (n == 0 && neo == 0) break;
         nmax = n;
+        npend = n + neo;
       }
     }
     ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET;
@@ -1528,7 +1615,7 @@ static int fd_chunk_run(const StepPlan& plan, FdChunk* ch) {
   CHKCH(ch, hipSetDevice(c->device));
   KArgs ka = plan.ka;
   CArgs ca = plan.ca;
-  ka.glist = ch->d_glist; ka.gcount = ch->gcount;
+  ka.glist = ch->d_glist; ka.gcount = ch->gcount; ka.map = ch->map;
   ca.c0 = ch->c0; ca.ccount = ch->ccount;
   const bool trace = getenv("VICGPU_TRACE") != nullptr;      // tuning: per-step wall time and Brent rounds (adds a sync per step)
   for (int s = plan.step0; s < plan.step0 + plan.nsteps; s++) {
@@ -1579,9 +1666,9 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   if (opt->FROZEN_SOIL && opt->QUICK_FLUX) return VICGPU_ERR_ARG;            // get_global_param.c:376-381
   // options of the reference this library does not implement are refused, never silently replaced
   // QUICK_SOLVE (calc_surf_energy_bal.c:289-309, 400-480; ignored with QUICK_FLUX like in the reference): the reference forces
-  // NOFLUX and EXP_TRANS off for the iteration and keeps whatever it last set for the final evaluation -- implemented for
-  // runs that have both off; not combined with IMPLICIT
-  if (opt->QUICK_SOLVE && !opt->QUICK_FLUX && (opt->NOFLUX || opt->EXP_TRANS || opt->IMPLICIT)) return VICGPU_ERR_UNSUPPORTED;
+  // NOFLUX and EXP_TRANS off for the iteration and keeps whatever it last set for the final evaluation (NOFLUX returns with a
+  // second iteration, EXP_TRANS never does): reproduced; not combined with IMPLICIT
+  if (opt->QUICK_SOLVE && !opt->QUICK_FLUX && opt->IMPLICIT) return VICGPU_ERR_UNSUPPORTED;
   // IMPLICIT (newt_raph_func_fast.c): the finite-difference soil profile with the node freezing parameters of the node
   // arrays; the reference as shipped reads the 3-element layer arrays out of bounds there (frozen_soil.c:283-284)
   if (opt->IMPLICIT && (opt->QUICK_FLUX || opt->frozen_compat)) return VICGPU_ERR_UNSUPPORTED;
@@ -1601,6 +1688,9 @@ int vicgpu_create(const vicgpu_options* opt, int device, vicgpu_ctx** out) {
   o.TEMP_TH_TYPE = opt->TEMP_TH_TYPE; o.GLACIER_ID = opt->GLACIER_ID; o.GLACIER_DYNAMICS = opt->GLACIER_DYNAMICS;
   o.frozen_compat = opt->frozen_compat; o.nveg_types = opt->nveg_types; o.wind_h = opt->wind_h; o.CORRPREC = opt->CORRPREC;
   o.BLOWING = opt->BLOWING ? 1 : 0; o.IMPLICIT = opt->IMPLICIT; o.QUICK_SOLVE = (opt->QUICK_SOLVE && !opt->QUICK_FLUX) ? 1 : 0;
+  // calc_surf_energy_bal.c:300-308: with QUICK_SOLVE and a surface energy balance the solver's EXP_TRANS is FALSE from the first
+  // iteration to the final evaluation (the linear-spacing coefficients on the run's node geometry, whatever it is)
+  if (o.QUICK_SOLVE && o.FULL_ENERGY) o.EXP_TRANS = 0;
   if (hipSetDevice(device) != hipSuccess) { delete c; return VICGPU_ERR_HIP; }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess
@@ -1757,6 +1847,11 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
       const int pct = atoi(ev);
       if (pct >= 5 && pct <= 100) c->profile_waves = c->profile_waves * pct / 100 > 0 ? c->profile_waves * pct / 100 : 1;
     }
+    // tuning: the pending share (percent of the chunk's HRUs) from which the evaluation rounds run from the pending list; 0 = never
+    if (const char* ev = getenv("VICGPU_EVAL_LIST_PCT")) {
+      const int pct = atoi(ev);
+      if (pct >= 0 && pct <= 100) c->eval_list_pct = pct;
+    }
     // cell chunks (VICGPU_CHUNKS): independent pipelines on their own streams and host threads.  Every kernel of the pipeline
     // is stalled most of its time (dependent fp64 chains in the profile kernel, memory latency in the others: 15 % VALU-active
     // per wave), so two pipelines side by side fill each other's gaps and thin tail rounds: -6 % step time at 2.5 M HRUs
@@ -1775,12 +1870,26 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
       std::vector<int> gl(cell_hru_list + cell_hru_offset[ch.c0], cell_hru_list + cell_hru_offset[ch.c0 + ch.ccount]);
       std::sort(gl.begin(), gl.end());
       ch.gcount = (int)gl.size();
+      ch.map = LaunchMap();
+      if (ch.ccount > 0 && ch.gcount % ch.ccount == 0 && !getenv("VICGPU_NO_XCD_MAP")) {
+        const int nslot = ch.gcount / ch.ccount;
+        bool regular = true;
+        for (int sl = 0; sl < nslot && regular; sl++)
+          for (int i = 0; i < ch.ccount; i++)
+            if (gl[(size_t)sl * ch.ccount + i] != sl * ncell + ch.c0 + i || hpi[(size_t)HPI_CELL * nhru + gl[(size_t)sl * ch.ccount + i]] != ch.c0 + i) {
+              regular = false;
+              break;
+            }
+        if (regular) { ch.map.nslot = nslot; ch.map.ccount = ch.ccount; }
+      }
       const size_t gb = sizeof(int) * (size_t)(ch.gcount > 0 ? ch.gcount : 1);
       HIPCHK(c, hipMalloc(&ch.d_glist, gb));
       ch.list_cap = ch.gcount > 0 ? ch.gcount : 1;
       HIPCHK(c, hipMalloc(&ch.d_list[0], gb * NBUCKET));
       HIPCHK(c, hipMalloc(&ch.d_list[1], gb * NBUCKET));
       HIPCHK(c, hipMalloc(&ch.d_count, sizeof(int) * CNT_TOTAL));
+      HIPCHK(c, hipMalloc(&ch.d_elist[0], gb));
+      HIPCHK(c, hipMalloc(&ch.d_elist[1], gb));
       if (c->o.IMPLICIT) {
         HIPCHK(c, hipMalloc(&ch.d_fb_list, gb * NBUCKET));
         HIPCHK(c, hipMalloc(&ch.d_fb_count, sizeof(int) * NBUCKET));
