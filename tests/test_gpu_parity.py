@@ -403,6 +403,33 @@ def test_chunking_is_invisible(monkeypatch):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize("case", ["frozen_fixed", "frozen_wb_daily"])
+def test_launch_shapes_are_invisible(monkeypatch, case):
+    """How the evaluation rounds are launched is tuning, not physics: dense rounds in XCD-aware block order or in plain order,
+    sparse rounds from the pending lists from the first round on (threshold 100 %) or never (0 %), must not change a single
+    bit -- HRUs never interact and every HRU sees the same sequence of operations whichever wave it rides in."""
+    from vic_amd.api import Model
+    kw, ncell, ntile, doy = CASES[case]
+    nsteps = 12 if kw.get("dt", 1) == 1 else 4
+    d, f, sf, dmy, sd0, si0 = _setup(kw, 200, ntile, nsteps, doy)
+    out = []
+    for env in ({}, {"VICGPU_EVAL_LIST_PCT": "100"}, {"VICGPU_EVAL_LIST_PCT": "0"}, {"VICGPU_NO_XCD_MAP": "1", "VICGPU_EVAL_LIST_PCT": "40"}):
+        for k in ("VICGPU_EVAL_LIST_PCT", "VICGPU_NO_XCD_MAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = Model(d)
+        m.set_state(sd0, si0)
+        m.push_forcing(f, sf, dmy)
+        m.dist_prec(0, nsteps)
+        sd, si = m.get_state()
+        out.append((sd, si, m.get_fluxes(), m.get_accum(), m.get_cell_errors()))
+        del m
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
 def _cfg3(ncell, nsteps, name="cfg3"):
     """The bench workloads as bench.py builds them: cfg3 = BASELINE.json configs[2] (FULL_ENERGY + FROZEN_SOIL, 10 nodes,
     5 bands x 5 tiles), cfg4 = one GPU's share of configs[3] (cfg3 + a glacier HRU in the top band of every cell)."""

@@ -41,6 +41,7 @@ namespace vic {
 #define PROFILE_NBUCKET (2 * (VIC_MAX_NODES + 2))
 #endif
 constexpr int NBUCKET = PROFILE_NBUCKET;
+static_assert(NBUCKET <= 64, "one lane per work-list segment when the pending total is summed");
 
 struct PArgs {
   const double* __restrict__ pin;    // item blocks [nhru][Nn][PREC]
@@ -53,6 +54,11 @@ struct PArgs {
   int* next;                         // work-list cursor (zero at launch; the evaluation kernel clears it again)
   int* count_zero;                   // segment counters [NBUCKET] of the list the following evaluation kernel appends to (cleared here)
   int* evalonly_zero;                // counter of HRUs whose next evaluation needs no solve (cleared here)
+  // the number of evaluations pending after this kernel = entries of the round's work list + evaluation-only HRUs of the round
+  // before, summed here (block 0) into ONE word on its own cache line for the waves of the evaluation kernel
+  const int* pend_counts;            // [NBUCKET] (the round's list; not `count` when this launch works on IMPLICIT's fall-back list)
+  const int* pend_eo;
+  int* pend_out;
   int Nn, NOFLUX, EXP_TRANS, TFALLBACK;
   const int* jl;                     // QUICK_SOLVE: [nhru] nodes 1 .. jl - 1 are solved (calc_surf_energy_bal.c:289-299), or null: all
 };
@@ -336,6 +342,10 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(PROFILE_REG_WAVES, PROFILE_REG
   if (blockIdx.x == 0) {
     for (int b = lane; b < NBUCKET; b += 64) a.count_zero[b] = 0;
     if (lane == 0) *a.evalonly_zero = 0;
+    int v = (lane < NBUCKET) ? a.pend_counts[lane] : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl(v, lane ^ off);
+    if (lane == 0) *a.pend_out = v + *a.pend_eo;
   }
   __syncthreads();
   int n = 0;
@@ -492,6 +502,10 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(LS_WAVES, LS_WAVES) void vic_p
   if (blockIdx.x == 0) {
     for (int b = lane; b < NBUCKET; b += 64) a.count_zero[b] = 0;
     if (lane == 0) *a.evalonly_zero = 0;
+    int v = (lane < NBUCKET) ? a.pend_counts[lane] : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl(v, lane ^ off);
+    if (lane == 0) *a.pend_out = v + *a.pend_eo;
   }
   __syncthreads();
   int n = 0;

@@ -887,12 +887,13 @@ struct EArgs {
   int* profile_next;     // work-list cursor of the profile kernel, cleared for its next launch
   int* evalonly;         // HRUs that wait for an evaluation without a solve (final evaluation on record)
   int* eo_list_next;     // ... and which: with the work list this is every HRU the round leaves pending
-  // sparse rounds (null in the dense ones, which go through glist / map and test hstate): lane = pending HRU, taken from the
-  // work list the profile kernel has just gone through and from the evaluation-only list of the round before
+  // sparse rounds (at most list_thr HRUs pending; the others go through glist / map and test hstate): lane = pending HRU, taken
+  // from the work list the profile kernel has just gone through and from the evaluation-only list of the round before
+  int list_thr;
   const int* list_cur;
   const int* count_cur;  // [NBUCKET]
   const int* eo_list_cur;
-  const int* eo_count_cur;
+  const int* npend_cur;  // their sum + the length of eo_list_cur, written by the round's profile kernel
   int implicit;          // IMPLICIT: the final evaluation is always solved again (its fallback flags depend on the solves before it)
   const double* veglib;  // for the table-derived part of the residual's inputs (surf_cell_fill)
   const double* forcing; // this step
@@ -904,10 +905,14 @@ struct EArgs {
 #endif
 __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(VIC_EVAL_WAVES, VIC_EVAL_WAVES) void vic_surf_eval(const EArgs a) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.profile_next = 0;
+  // Sparse rounds.  A dense launch pays a whole wave -- its chain of dependent loads -- for every 64 HRUs of which one is
+  // pending.  The number pending is on the device before the host knows it (the work list the profile kernel has just gone
+  // through + the evaluation-only list of the round before), so every wave looks at it: from the round in which at most
+  // list_thr HRUs are pending, lane = entry of those lists and the waves beyond the lists' end leave at once.
+  const int npend = *a.npend_cur;
   int g;
-  if (a.list_cur) {
-    // Sparse round: one lane per pending HRU.  A dense launch pays a whole wave -- its chain of dependent loads -- for every
-    // 64 HRUs of which one is pending; from the round in which few are, the waves are formed from the lists instead.
+  if (npend <= a.list_thr) {
+    if ((int)blockIdx.x * 64 >= npend) return;
     __shared__ int bcount[NBUCKET];
     for (int b = threadIdx.x; b < NBUCKET; b += 64) bcount[b] = a.count_cur[b];
     __syncthreads();
@@ -915,7 +920,7 @@ __global__ __launch_bounds__(64) VIC_WAVES_PER_EU(VIC_EVAL_WAVES, VIC_EVAL_WAVES
 #pragma unroll 1
     for (int b = 0; b < NBUCKET; b++) nsolve += bcount[b];
     const int gi = blockIdx.x * 64 + threadIdx.x;
-    if (gi >= nsolve + *a.eo_count_cur) return;
+    if (gi >= npend) return;
     if (gi < nsolve) {
       int rem = gi, found = 0;
 #pragma unroll 1
@@ -1311,7 +1316,7 @@ struct FdChunk {
   LaunchMap map;                   // XCD-aware launch order when the chunk's list is regular (slot-major, every slot ccount cells)
   int* d_list[2] = {nullptr, nullptr};   // work lists (HRU ids)
   int *d_fb_list = nullptr, *d_fb_count = nullptr;   // IMPLICIT: HRUs whose Newton iteration failed this round
-  int* d_count = nullptr;          // [l * NBUCKET + b] segment sizes of list l, then CNT_CURSOR, CNT_EVALONLY + l
+  int* d_count = nullptr;          // counter block (CNT_*): segment sizes of the two lists, profile cursor, evaluation-only counts, pending total
   int* d_elist[2] = {nullptr, nullptr};  // evaluation-only lists (flat, gcount entries): pending HRUs that need no solve
   int list_cap = 0;                // entries per segment
   int* h_count = nullptr;          // pinned read-back, RB_DEPTH slots of CNT_TOTAL
@@ -1364,7 +1369,7 @@ struct vicgpu_ctx {
   int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr, *d_lastexp = nullptr, *d_jl = nullptr;
   double* d_pimp = nullptr;        // IMPLICIT only
   int profile_waves = 0;           // resident waves of the profile kernel
-  int eval_list_pct = 25;          // the evaluation kernel runs from the pending list once at most this share of the HRUs is pending
+  int eval_list_pct = 4;           // sparse evaluation rounds (lane = pending HRU) once at most this percentage of the HRUs is pending
   bool node_newton = false;        // frozen-node root finder: safeguarded Newton instead of the reference's Brent iteration
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
@@ -1468,7 +1473,13 @@ static int profile_resident_waves(int device, bool newton) {
     }                                                                                                  \
   } while (0)
 
-constexpr int CNT_CURSOR = 2 * NBUCKET, CNT_EVALONLY = 2 * NBUCKET + 1, CNT_TOTAL = 2 * NBUCKET + 3;    // CNT_EVALONLY + l: of list l
+// Counter block of a chunk.  Every group sits on its own 128-byte lines: the evaluation kernel's waves all read the pending
+// count while others append to the next list with atomics, and reads that share a line with those atomics queue behind them
+// in the L2 channel (measured: the dense evaluation rounds went from 0.6 to 1.4-2.5 ms when they did).
+constexpr int CNT_LIST_STRIDE = 64, CNT_CURSOR = 128, CNT_EVALONLY = 160, CNT_EVALONLY_STRIDE = 32, CNT_NPEND = 224, CNT_TOTAL = 256;
+static_assert(NBUCKET <= CNT_LIST_STRIDE, "counter block layout");
+static inline int* cnt_list(int* d_count, int l) { return d_count + l * CNT_LIST_STRIDE; }
+static inline int* cnt_evalonly(int* d_count, int l) { return d_count + CNT_EVALONLY + l * CNT_EVALONLY_STRIDE; }
 
 // One model step of the finite-difference pipeline for one chunk (see the header of this file).  Blocks the calling
 // host thread: the number of Brent rounds is data dependent, so the pending count is read back once the first rounds
@@ -1477,9 +1488,9 @@ static int fd_read_count(FdChunk* ch, int which, int* nsolve, int* nevalonly) {
   CHKCH(ch, hipMemcpyAsync(ch->h_count, ch->d_count, sizeof(int) * CNT_TOTAL, hipMemcpyDeviceToHost, ch->stream));
   CHKCH(ch, hipStreamSynchronize(ch->stream));
   int n = 0;
-  for (int b = 0; b < NBUCKET; b++) n += ch->h_count[which * NBUCKET + b];
+  for (int b = 0; b < NBUCKET; b++) n += ch->h_count[which * CNT_LIST_STRIDE + b];
   *nsolve = n;
-  *nevalonly = ch->h_count[CNT_EVALONLY + which];
+  *nevalonly = ch->h_count[CNT_EVALONLY + which * CNT_EVALONLY_STRIDE];
   return VICGPU_OK;
 }
 
@@ -1490,7 +1501,7 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   if (c->any_glacier) CHKCH(ch, (n10 ? launch_hru<10>(ka, st, false, true) : launch_hru<VIC_MAX_NODES>(ka, st, false, true)));
   CHKCH(ch, hipMemsetAsync(ch->d_count, 0, sizeof(int) * CNT_TOTAL, st));
   int cur = 0;
-  ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET; ka.list_cap = ch->list_cap;
+  ka.phase = 0; ka.list = ch->d_list[cur]; ka.count = cnt_list(ch->d_count, cur); ka.list_cap = ch->list_cap;
   CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
   PArgs pa;
   pa.pin = c->d_pin; pa.ts = c->d_ts; pa.pout = c->d_pout; pa.pslot = c->d_pslot; pa.Nn = Nn; pa.NOFLUX = c->o.NOFLUX; pa.EXP_TRANS = c->o.EXP_TRANS;
@@ -1500,8 +1511,10 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
   ea.cell_params = c->d_cp; ea.hpi = c->d_hpi; ea.ctx = c->d_ctx;
   ea.ctx_words = n10 ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
   ea.pout = c->d_pout; ea.pslot = c->d_pslot; ea.ts = c->d_ts; ea.hstate = c->d_hstate; ea.profile_next = ch->d_count + CNT_CURSOR;
+  ea.list_thr = (int)((long long)ch->gcount * c->eval_list_pct / 100);
   ea.list_cap = ch->list_cap; ea.hkey = c->d_hkey; ea.implicit = c->o.IMPLICIT; ea.jl = c->d_jl;
   ea.veglib = c->d_veglib; ea.forcing = ka.forcing; ea.month = ka.dmy.month;
+  const bool trace_rounds = getenv("VICGPU_TRACE_ROUNDS") != nullptr;
   const int FREE_ROUNDS = 6;       // a Brent solve needs two bracket evaluations, a few iterations and the final evaluation
   const int nsub = c->o.NF;
   for (int p = 1; p <= nsub; p++) {
@@ -1510,8 +1523,9 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
     int rb_list[RB_DEPTH];                     // the list each read-back slot counts
     int rb_first = -1;                         // first round whose counts were read back
     for (int round = 0;; round++) {
-      pa.list = ch->d_list[cur]; pa.count = ch->d_count + cur * NBUCKET; pa.count_zero = ch->d_count + (cur ^ 1) * NBUCKET;
-      pa.evalonly_zero = ch->d_count + CNT_EVALONLY + (cur ^ 1);
+      pa.list = ch->d_list[cur]; pa.count = cnt_list(ch->d_count, cur); pa.count_zero = cnt_list(ch->d_count, cur ^ 1);
+      pa.evalonly_zero = cnt_evalonly(ch->d_count, cur ^ 1);
+      pa.pend_counts = cnt_list(ch->d_count, cur); pa.pend_eo = cnt_evalonly(ch->d_count, cur); pa.pend_out = ch->d_count + CNT_NPEND;
       if (c->o.IMPLICIT) {
         // the Newton iteration for every listed HRU; those it fails for go on the fall-back list, which the explicit kernel
         // (the same one, on that list) solves right after (func_surf_energy_bal.c:192-222)
@@ -1525,19 +1539,21 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
       }
       CHKCH(ch, (n10 ? launch_profile<10>(pa, nmax, c->profile_waves, c->node_newton, st)
                      : launch_profile<VIC_MAX_NODES>(pa, nmax, c->profile_waves, c->node_newton, st)));
-      ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = ch->d_count + (cur ^ 1) * NBUCKET;
-      ea.evalonly = ch->d_count + CNT_EVALONLY + (cur ^ 1); ea.eo_list_next = ch->d_elist[cur ^ 1];
-      if (npend >= 0 && (long long)npend * 100 <= (long long)ch->gcount * c->eval_list_pct) {
-        ea.list_cur = ch->d_list[cur]; ea.count_cur = ch->d_count + cur * NBUCKET;
-        ea.eo_list_cur = ch->d_elist[cur]; ea.eo_count_cur = ch->d_count + CNT_EVALONLY + cur;
-        hipLaunchKernelGGL(vic_surf_eval, dim3((npend + 63) / 64 > 0 ? (npend + 63) / 64 : 1), dim3(64), 0, st, ea);
-      } else {
-        ea.list_cur = ea.count_cur = ea.eo_list_cur = ea.eo_count_cur = nullptr;
-        hipLaunchKernelGGL(vic_surf_eval, dim3(ea.map.nblocks(ch->gcount)), dim3(64), 0, st, ea);
-      }
+      ea.list_next = ch->d_list[cur ^ 1]; ea.count_next = cnt_list(ch->d_count, cur ^ 1);
+      ea.evalonly = cnt_evalonly(ch->d_count, cur ^ 1); ea.eo_list_next = ch->d_elist[cur ^ 1];
+      ea.list_cur = ch->d_list[cur]; ea.count_cur = cnt_list(ch->d_count, cur);
+      ea.eo_list_cur = ch->d_elist[cur]; ea.npend_cur = ch->d_count + CNT_NPEND;
+      // the device switches to the lists by itself; once the host knows (RB_LAG rounds late) that it has, the grid shrinks too
+      const bool sparse = npend >= 0 && npend <= ea.list_thr;
+      hipLaunchKernelGGL(vic_surf_eval, dim3(sparse ? ((npend + 63) / 64 > 0 ? (npend + 63) / 64 : 1) : ea.map.nblocks(ch->gcount)), dim3(64), 0, st, ea);
       CHKCH(ch, hipGetLastError());
       cur ^= 1;
       ch->rounds++;
+      if (trace_rounds) {       // tuning: what every round leaves pending (a host round trip per round)
+        int n = 0, ne = 0;
+        if (fd_read_count(ch, cur, &n, &ne) != VICGPU_OK) return VICGPU_ERR_HIP;
+        fprintf(stderr, "vicgpu rounds: chunk %d sub-step %d round %d leaves %d solves + %d evaluation-only of %d\n", (int)(ch - &c->chunks[0]), p, round, n, ne, ch->gcount);
+      }
       // The list sizes of this round travel to the host behind the kernels just launched; the host looks at the copy issued
       // RB_LAG rounds ago, which has long arrived, so waiting for it never leaves the GPU idle.  The counts only shrink from
       // round to round (an HRU either goes on or is through), so a stale count is a valid upper bound for the grid.
@@ -1553,14 +1569,14 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
         CHKCH(ch, hipEventSynchronize(ch->readback[slot]));
         const int* h = ch->h_count + slot * CNT_TOTAL;
         int n = 0;
-        for (int b = 0; b < NBUCKET; b++) n += h[rb_list[slot] * NBUCKET + b];
-        const int neo = h[CNT_EVALONLY + rb_list[slot]];
+        for (int b = 0; b < NBUCKET; b++) n += h[rb_list[slot] * CNT_LIST_STRIDE + b];
+        const int neo = h[CNT_EVALONLY + rb_list[slot] * CNT_EVALONLY_STRIDE];
         if (n == 0 && neo == 0) break;
         nmax = n;
         npend = n + neo;
       }
     }
-    ka.phase = p; ka.list = ch->d_list[cur]; ka.count = ch->d_count + cur * NBUCKET;
+    ka.phase = p; ka.list = ch->d_list[cur]; ka.count = cnt_list(ch->d_count, cur);
     CHKCH(ch, (n10 ? launch_fd_stage<10>(ka, c->o.NF > 1, st) : launch_fd_stage<VIC_MAX_NODES>(ka, c->o.NF > 1, st)));
     if (p < nsub) {
       int n = 0, ne = 0;
