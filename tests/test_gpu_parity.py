@@ -7,6 +7,8 @@ Tolerance.  All arithmetic is fp64 on both sides, but (i) device exp/log/pow dif
   * teacher-forced (oracle state in -> one step): 1e-6 relative on every prognostic and flux row,
   * free-running: 1e-5 relative on the headline outputs (runoff, baseflow, evap, SWE, soil moisture) accumulated per cell.
 """
+import os
+
 import numpy as np
 import pytest
 

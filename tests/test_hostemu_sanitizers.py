@@ -44,7 +44,7 @@ def test_monolithic_kernel_clean(hostemu_lib, poison):
     assert out.count("worst rel diff") == 5
 
 
-@pytest.mark.parametrize("poison", [False, True])
+@pytest.mark.parametrize("poison", [True])          # (the poisoned run checks everything the plain one does; one of them keeps the CPU suite short)
 def test_fd_pipeline_clean(hostemu_lib, poison):
     """vic_fd_stage -> { vic_profile_solve_reg ; vic_surf_eval } rounds -> vic_fd_stage, work lists included."""
     out = _run(*hostemu_lib, ["3", "2", "frozen_fixed", "frozen_compat", "glacier_frozen"], poison)
@@ -58,7 +58,7 @@ def test_fd_pipeline_newton_and_generic_kernel_clean(hostemu_lib):
     assert out.count("worst rel diff") == 3
 
 
-@pytest.mark.parametrize("poison", [False, True])
+@pytest.mark.parametrize("poison", [True])
 def test_round2_entry_points_clean(hostemu_lib, poison):
     """put_data (three kernels), state-file records (gather and scatter), forcing prefetch / swap with the on-device
     derivation of atmos[rec], and the IMPLICIT profile kernel with its explicit fall-back."""

@@ -11,6 +11,6 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 SANFLAGS="-fsanitize=address,undefined -shared-libsan -fno-omit-frame-pointer"
 OUT=$ROOT/tools/hostemu/libvicgpu_hostemu.so
 if [ "${SAN:-asan}" = "none" ]; then SANFLAGS=""; OUT=$ROOT/tools/hostemu/libvicgpu_hostemu_plain.so; fi
-$CXX ${EXTRA:-} -x c++ -std=c++17 -O1 -g -ffp-contract=off -fPIC -shared $SANFLAGS -Wno-unknown-attributes -Wno-ignored-attributes \
+$CXX ${EXTRA:-} -x c++ -std=c++17 -O1 -g -ffp-contract=off -ftrivial-auto-var-init=zero -fPIC -shared $SANFLAGS -Wno-unknown-attributes -Wno-ignored-attributes \
   -I$ROOT/tools/hostemu -I$ROOT/include -I$ROOT/vic_amd/csrc $ROOT/vic_amd/csrc/vicgpu_api.hip -o $OUT -lpthread
 echo $OUT
