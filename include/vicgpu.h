@@ -24,7 +24,7 @@
  * (Ndist = 1, mu = 1), no lakes, no EXCESS_ICE / SPATIAL_FROST / SPATIAL_SNOW /
  * QUICK_FS / LOW_RES_MOIST / CLOSE_ENERGY (all compiled out in the reference,
  * user_def.h:36-92).  CORRPREC, BLOWING, IMPLICIT (finite-difference soil profile, node-array
- * freezing parameters: frozen_compat = 0) and QUICK_SOLVE (with NOFLUX and EXP_TRANS off)
+ * freezing parameters: frozen_compat = 0) and QUICK_SOLVE (with NOFLUX / EXP_TRANS as the reference handles them)
  * are implemented.  What the device code does not implement (see vicgpu_create) is
  * REJECTED with VICGPU_ERR_UNSUPPORTED, never silently replaced.
  */
@@ -101,7 +101,8 @@ typedef struct vicgpu_options {
                                the explicit solver as its fallback; rejected with QUICK_FLUX or frozen_compat */
   int BLOWING;              /* options.BLOWING: sublimation from blowing snow (CalcBlowingSnow.c), once per snow sub-step */
   int QUICK_SOLVE;          /* options.QUICK_SOLVE (calc_surf_energy_bal.c:289-314, 400-475): ignored with QUICK_FLUX (as in the
-                               reference); rejected together with NOFLUX, EXP_TRANS or IMPLICIT */
+                               reference); the iteration runs with NOFLUX and EXP_TRANS forced off, NOFLUX comes back with a second
+                               iteration only, EXP_TRANS never (calc_surf_energy_bal.c:298-308, 403); rejected together with IMPLICIT */
   int NODE_SOLVER;          /* VIC_NODE_SOLVER_*: how the frozen-node heat balance (soil_thermal_eqn.c) is solved -- not a
                                reference option; BRENT replays root_brent.c's iteration, NEWTON converges to the same root */
   double wind_h;            /* global_param.wind_h (m) */
