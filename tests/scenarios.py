@@ -146,7 +146,39 @@ def random_combinations(n=14, seed=2026):
     return out
 
 
+def random_combinations_round3(n=10, seed=0x516D):
+    """A second batch for the options that arrived in round 3: BLOWING on any surface, QUICK_SOLVE with any NOFLUX / EXP_TRANS,
+    node counts up to 24 (IMPLICIT up to its own limit of 21), all drawn together with the older switches."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        frozen = bool(rng.integers(0, 3)) or k % 2 == 0
+        kw = dict(FULL_ENERGY=1, BLOWING=int(rng.integers(0, 3) > 0))
+        if frozen:
+            kw.update(FROZEN_SOIL=1, frozen_compat=0, Nnode=int(rng.choice([5, 10, 12, 21, 24])), NOFLUX=int(rng.integers(0, 2)),
+                      EXP_TRANS=int(rng.integers(0, 2)))
+            mode = rng.integers(0, 4)
+            if mode == 1 and kw["Nnode"] <= 21:
+                kw["IMPLICIT"] = 1
+            elif mode >= 2:
+                kw["QUICK_SOLVE"] = 1
+        elif rng.integers(0, 3) == 0:
+            kw = dict(FULL_ENERGY=0, dt=int(rng.choice([3, 24])), snow_step=3, BLOWING=1)
+        kw["Nband"] = int(rng.integers(1, 4))
+        kw["GRND_FLUX_TYPE"] = int(rng.choice([C["VIC_GF_406"], C["VIC_GF_410"], C["VIC_GF_FULL"]]))
+        kw["AERO_RESIST_CANSNOW"] = int(rng.choice([C["VIC_AR_406"], C["VIC_AR_406_LS"], C["VIC_AR_406_FULL"], C["VIC_AR_410"], C["VIC_AR_COMBO"]]))
+        kw["SNOW_DENSITY"] = int(rng.integers(0, 2)); kw["SNOW_ALBEDO"] = int(rng.integers(0, 2)); kw["TEMP_TH_TYPE"] = int(rng.integers(0, 2))
+        kw["CORRPREC"] = int(rng.integers(0, 2)); kw["TFALLBACK"] = int(rng.integers(0, 4) > 0)
+        glacier = bool(rng.integers(0, 3) == 0) and kw["Nband"] > 1
+        if glacier:
+            kw["GLACIER_DYNAMICS"] = int(rng.integers(0, 2))
+        out.append(("combo3_%02d" % k, dict(kw=kw, variant="fixed" if kw.get("FROZEN_SOIL") else "plain", ncell=5, ntile=2, glacier=glacier,
+                                            nsteps=24, doy=int(rng.choice([20, 95, 330, 350])), tweak="windy" if kw.get("BLOWING") else None)))
+    return out
+
+
 RANDOM_COMBINATIONS = dict(random_combinations())
+RANDOM_COMBINATIONS.update(random_combinations_round3())
 
 
 def all_scenarios():

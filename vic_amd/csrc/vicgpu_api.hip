@@ -115,39 +115,38 @@ struct KArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ parked context
-// Plain structs are parked word by word.  The table is tiled by wave: [hru / 64][word][hru % 64], so one wave's whole
-// context is a single contiguous slab (coalesced 512-byte rows, a handful of pages) instead of one row per word
-// spread over the whole table.
+// Plain structs are parked word by word.  The table is tiled by wave: one wave's whole context is a single contiguous slab
+// (a handful of pages) instead of one row per word spread over the whole table, and inside the slab every lane owns runs of
+// VIC_CTX_GROUP consecutive words: [hru / 64][word / G][hru % 64][G].  G = 1 is the plain [word][lane] tiling (8-byte-per-lane
+// rows run the load path at half its rate); G = 2 makes every access 16 bytes; G = 8 gives a lane whole 64-byte sectors, so a
+// wave formed from the pending lists (sparse rounds: lane = pending HRU, 64 different slabs) wastes nothing of what it
+// fetches, while a dense wave still reads its slab front to back (its 16-byte accesses, 64 bytes apart, fill the same lines
+// over four instructions): dense rounds unchanged, sparse rounds cheap enough to start at 30 % pending instead of 4 %
+// (24.5 / 24.65 vs 24.9 / 25.0 ms per step against G = 2; G = 16 and 32 measure the same within noise).
 #ifndef VIC_CTX_AOS
 #define VIC_CTX_AOS 0
 #endif
-#ifndef VIC_CTX_PAIR
-#define VIC_CTX_PAIR 1
+#ifndef VIC_CTX_GROUP
+#define VIC_CTX_GROUP 8
 #endif
-// Word W of HRU g:  AOS   [hru][word]                        one HRU's context is one contiguous block
-//                   PAIR  [hru / 64][word / 2][hru % 64][2]  a wave's slab; a lane's words come in adjacent pairs, so two
-//                                                            consecutive words of a struct are one 16-byte access per lane
-//                                                            (128-byte lines per 8 lanes; 8-byte-per-lane rows run the
-//                                                            load path at half its rate)
-//                   else  [hru / 64][word][hru % 64]
+// Word W of HRU g:  AOS    [hru][word]                        one HRU's context is one contiguous block (measured in round 2:
+//                                                             sparse rounds -35 %, dense rounds +23 %)
+//                   else   [hru / 64][word / G][hru % 64][G]
+constexpr size_t ctx_padded_words(size_t words) { return (words + VIC_CTX_GROUP - 1) / VIC_CTX_GROUP * VIC_CTX_GROUP; }
 struct CtxRef {
   unsigned long long* p;    // word 0 of this HRU
   VIC_DEV static CtxRef at(unsigned long long* base, size_t words_per_hru, size_t g) {
 #if VIC_CTX_AOS
     return CtxRef{base + g * words_per_hru};
-#elif VIC_CTX_PAIR
-    return CtxRef{base + (g >> 6) * (((words_per_hru + 1) & ~(size_t)1) * 64) + (g & 63) * 2};
 #else
-    return CtxRef{base + (g >> 6) * (words_per_hru * 64) + (g & 63)};
+    return CtxRef{base + (g >> 6) * (ctx_padded_words(words_per_hru) * 64) + (g & 63) * VIC_CTX_GROUP};
 #endif
   }
   VIC_DEV unsigned long long* word(size_t W) const {
 #if VIC_CTX_AOS
     return p + W;
-#elif VIC_CTX_PAIR
-    return p + (W >> 1) * 128 + (W & 1);
 #else
-    return p + W * 64;
+    return p + (W / VIC_CTX_GROUP) * (64 * VIC_CTX_GROUP) + (W % VIC_CTX_GROUP);
 #endif
   }
 };
@@ -1369,7 +1368,7 @@ struct vicgpu_ctx {
   int *d_hstate = nullptr, *d_pslot = nullptr, *d_hkey = nullptr, *d_lastexp = nullptr, *d_jl = nullptr;
   double* d_pimp = nullptr;        // IMPLICIT only
   int profile_waves = 0;           // resident waves of the profile kernel
-  int eval_list_pct = 4;           // sparse evaluation rounds (lane = pending HRU) once at most this percentage of the HRUs is pending
+  int eval_list_pct = 30;          // sparse evaluation rounds (lane = pending HRU) once at most this percentage of the HRUs is pending
   bool node_newton = false;        // frozen-node root finder: safeguarded Newton instead of the reference's Brent iteration
   std::vector<FdChunk> chunks;     // cell chunks, each an independent pipeline on its own stream
   int ev_steps = 0;                // steps covered by the event pair of the last vicgpu_step call
@@ -1830,7 +1829,7 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
   if (c->fd) {
     const int Nn = c->o.Nnode;
     const size_t words = (Nn == 10) ? ctx_words<10>() : ctx_words<VIC_MAX_NODES>();
-    HIPCHK(c, hipMalloc(&c->d_ctx, sizeof(unsigned long long) * ((words + 1) & ~(size_t)1) * (((size_t)nhru + 63) / 64 * 64)));
+    HIPCHK(c, hipMalloc(&c->d_ctx, sizeof(unsigned long long) * ctx_padded_words(words) * (((size_t)nhru + 63) / 64 * 64)));
     HIPCHK(c, hipMalloc(&c->d_pin, sizeof(double) * (size_t)Nn * PREC * nhru));
     HIPCHK(c, hipMalloc(&c->d_ts, sizeof(double) * nhru));
     HIPCHK(c, hipMalloc(&c->d_pout, sizeof(double) * (size_t)pout_hru_stride(Nn) * nhru));
