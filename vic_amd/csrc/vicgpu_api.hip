@@ -117,36 +117,48 @@ struct KArgs {
 // ------------------------------------------------------------------------------------------------ parked context
 // Plain structs are parked word by word.  The table is tiled by wave: one wave's whole context is a single contiguous slab
 // (a handful of pages) instead of one row per word spread over the whole table, and inside the slab every lane owns runs of
-// VIC_CTX_GROUP consecutive words: [hru / 64][word / G][hru % 64][G].  G = 1 is the plain [word][lane] tiling (8-byte-per-lane
-// rows run the load path at half its rate); G = 2 makes every access 16 bytes; G = 8 gives a lane whole 64-byte sectors, so a
-// wave formed from the pending lists (sparse rounds: lane = pending HRU, 64 different slabs) wastes nothing of what it
-// fetches, while a dense wave still reads its slab front to back (its 16-byte accesses, 64 bytes apart, fill the same lines
-// over four instructions): dense rounds unchanged, sparse rounds cheap enough to start at 30 % pending instead of 4 %
-// (24.5 / 24.65 vs 24.9 / 25.0 ms per step against G = 2; G = 16 and 32 measure the same within noise).
+// G consecutive words: [hru / 64][word / G][hru % 64][G].  G = 1 is the plain [word][lane] tiling (8-byte-per-lane rows run
+// the load path at half its rate); G = 2 makes every access 16 bytes; G = 8 gives a lane whole 64-byte sectors, so a wave
+// formed from the pending lists (sparse rounds: lane = pending HRU, 64 different slabs) wastes nothing of what it fetches,
+// while a dense wave still reads its slab front to back (its 16-byte accesses, 64 bytes apart, fill the same lines over four
+// instructions).  Measured, same box: evaluation kernel 6.8 vs 7.7-8.0 ms per step with the sparse rounds starting at 30 %
+// pending instead of 4 %; the opening stage, which WRITES the context, 4.7-4.9 vs 4.3-4.5 ms.  So the slab has two regions:
+// what the evaluation kernel reads (SurfSolve, SurfEBMut, SurfEBConst: words below CTX_NA) in groups of VIC_CTX_GROUP = 8, what
+// only the two stage kernels exchange (everything after) in pairs.  (G = 16 and 32 measure like 8, G = 4 worse than 2.)
 #ifndef VIC_CTX_AOS
 #define VIC_CTX_AOS 0
 #endif
 #ifndef VIC_CTX_GROUP
 #define VIC_CTX_GROUP 8
 #endif
+#ifndef VIC_CTX_GROUP_B
+#define VIC_CTX_GROUP_B 2
+#endif
 // Word W of HRU g:  AOS    [hru][word]                        one HRU's context is one contiguous block (measured in round 2:
 //                                                             sparse rounds -35 %, dense rounds +23 %)
-//                   else   [hru / 64][word / G][hru % 64][G]
-constexpr size_t ctx_padded_words(size_t words) { return (words + VIC_CTX_GROUP - 1) / VIC_CTX_GROUP * VIC_CTX_GROUP; }
+//                   else   region A [hru / 64][W / G][hru % 64][G], then region B the same with G_B and W - CTX_NA
+constexpr size_t CTX_NA = sizeof(SurfSolve) / 8 + sizeof(SurfEBMut) / 8 + offsetof(SurfEBConst, Cs2) / 8;
+constexpr size_t CTX_NA_PAD = (CTX_NA + VIC_CTX_GROUP - 1) / VIC_CTX_GROUP * VIC_CTX_GROUP;
+constexpr size_t ctx_padded_words(size_t words) {      // slab words per lane
+  return CTX_NA_PAD + ((words > CTX_NA ? words - CTX_NA : 0) + VIC_CTX_GROUP_B - 1) / VIC_CTX_GROUP_B * VIC_CTX_GROUP_B;
+}
 struct CtxRef {
-  unsigned long long* p;    // word 0 of this HRU
+  unsigned long long* p;    // word 0 of this HRU (AOS) / of this HRU's wave slab
+  int lane;
   VIC_DEV static CtxRef at(unsigned long long* base, size_t words_per_hru, size_t g) {
 #if VIC_CTX_AOS
-    return CtxRef{base + g * words_per_hru};
+    return CtxRef{base + g * words_per_hru, 0};
 #else
-    return CtxRef{base + (g >> 6) * (ctx_padded_words(words_per_hru) * 64) + (g & 63) * VIC_CTX_GROUP};
+    return CtxRef{base + (g >> 6) * (ctx_padded_words(words_per_hru) * 64), (int)(g & 63)};
 #endif
   }
   VIC_DEV unsigned long long* word(size_t W) const {
 #if VIC_CTX_AOS
     return p + W;
 #else
-    return p + (W / VIC_CTX_GROUP) * (64 * VIC_CTX_GROUP) + (W % VIC_CTX_GROUP);
+    if (W < CTX_NA) return p + (W / VIC_CTX_GROUP) * (64 * VIC_CTX_GROUP) + lane * VIC_CTX_GROUP + (W % VIC_CTX_GROUP);
+    const size_t V = W - CTX_NA;
+    return p + CTX_NA_PAD * 64 + (V / VIC_CTX_GROUP_B) * (64 * VIC_CTX_GROUP_B) + lane * VIC_CTX_GROUP_B + (V % VIC_CTX_GROUP_B);
 #endif
   }
 };
@@ -187,6 +199,7 @@ constexpr size_t CO_SV = 0, CO_EBM = CO_SV + CW_SV, CO_EBC = CO_EBM + CW_EBM, CO
 constexpr size_t CW_W = sizeof(WCarry) / 8, CO_WM = CO_W + CW_W;
 template <int NN> constexpr size_t ctx_words() { return CO_WM + sizeof(WCarryMulti<NN>) / 8; }
 static_assert(sizeof(StepConstPost) <= sizeof(StepConst), "StepConstPost is parked in StepConst's words");
+static_assert(CTX_NA == CO_P, "region A of the context slab = what the evaluation kernel reads");
 // SubLoop in two parts: the head always, the sub-step sums only once a sub-step has been booked (they are zero before)
 constexpr size_t CW_L_HEAD = offsetof(SubLoop, st_AlbedoOver) / 8;
 // SurfSolve: the Brent state and the abscissa (rewritten by every evaluation), then the rest
