@@ -22,6 +22,9 @@ CASES = [
     # COMPUTE_TREELINE result in the cell table: the top band of every other cell is above the tree line (put_data.c:185-208,
     # 289-290: overstory HRUs there are left out, the others weighted up)
     ("treeline", dict(FULL_ENERGY=1, Nband=3), "plain", 8, 3, False, 36, 70, 4),
+    # BLOWING (wind x 3.5, so that transport happens): OUT_SUB_BLOWING / OUT_SUB_SURFACE / OUT_SUB_SNOW and their band variables
+    ("blowing_bands", dict(FULL_ENERGY=1, Nband=2, BLOWING=1), "plain", 6, 3, False, 72, 350, 6),
+    ("blowing_glacier_frozen", dict(FROZEN, Nband=2, BLOWING=1), "fixed", 4, 2, True, 48, 20, 4),
 ]
 AGG = {0: "AGG_TYPE_AVG", 1: "AGG_TYPE_BEG", 2: "AGG_TYPE_END", 3: "AGG_TYPE_MAX", 4: "AGG_TYPE_MIN", 5: "AGG_TYPE_SUM"}   # vicNl_def.h
 
@@ -65,6 +68,8 @@ def test_oracle_put_data_vs_reference(case, oracle_lib, ref_available):
     f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
     if name == "stress_fallback":
         f[5::7, C["VIC_F_SHORTWAVE"]][..., np.arange(d.ncell) % 3 == 1] = 60000.0
+    if name.startswith("blowing"):
+        f[:, C["VIC_F_WIND"]] *= 3.5
     ref = oracle_lib.RefModel(d, variant)
     ref.init_state(f[0], dmy[0], d.init_moist)
     sd0, si0 = ref.get_state()
@@ -81,6 +86,7 @@ def test_oracle_put_data_vs_reference(case, oracle_lib, ref_available):
     ref.reset_agg(); orc.reset_agg()
     assert np.array_equal(ref.get_balance(), orc.get_balance())
     step_in_interval = 0
+    blowing_seen = 0.0
     for s in range(nsteps):
         fr, cr, er = ref.step(f[s], sf[s], dmy[s])
         fo, co, eo = orc.step(f[s], sf[s], dmy[s])
@@ -93,6 +99,8 @@ def test_oracle_put_data_vs_reference(case, oracle_lib, ref_available):
                 assert np.array_equal(a, b, equal_nan=True), "step %d %s %s: worst %.3e (%r vs %r)" % (
                     s, n, "aggdata" if agg else "data", rel_diff(a, b, 1e-300).max(), a.ravel()[:3], b.ravel()[:3])
         assert np.array_equal(ref.get_balance(), orc.get_balance(), equal_nan=True), "step %d bookkeeping" % s
+        if "OUT_SUB_BLOWING" in names:
+            blowing_seen = max(blowing_seen, float(np.nanmax(np.abs(orc.get_output("OUT_SUB_BLOWING", False)))))
         if step_in_interval == ratio:           # vicNl.c:596-608
             ref.reset_agg(); orc.reset_agg()
             step_in_interval = 0
@@ -101,6 +109,8 @@ def test_oracle_put_data_vs_reference(case, oracle_lib, ref_available):
         assert np.abs(pb[C["PB_WATER_CUM_ERROR"]]).max() < 1e-6        # the model closes its water balance
     if name == "stress_fallback":
         assert pb[C["PB_FB_TSURF"]].max() > 0
+    if name.startswith("blowing"):
+        assert blowing_seen > 0                                          # sublimation from blowing snow did reach the outputs
     ref.close()
 
 
@@ -116,6 +126,8 @@ GPU_CASES = [
     ("irregular", dict(FULL_ENERGY=1, Nband=3), 24, 3, False, 24, 70, 4, "brent"),
     ("irregular_frozen", dict(FROZEN, Nband=3), 12, 3, False, 12, 80, 3, "brent"),
     ("treeline", dict(FULL_ENERGY=1, Nband=3), 40, 3, False, 24, 70, 4, "brent"),
+    ("blowing_bands", dict(FULL_ENERGY=1, Nband=2, BLOWING=1), 40, 3, False, 36, 350, 6, "brent"),
+    ("blowing_glacier_frozen", dict(FROZEN, Nband=2, BLOWING=1), 12, 2, True, 24, 20, 4, "newton"),
 ]
 # differences of nearly equal storages and balance residuals: compared absolutely (mm, W/m2)
 DIFF_VARS = ("OUT_DELSOILMOIST", "OUT_DELSWE", "OUT_DELINTERCEPT", "OUT_DELSURFSTOR", "OUT_WATER_ERROR", "OUT_ENERGY_ERROR")
@@ -153,6 +165,8 @@ def test_device_put_data_against_oracle(case, oracle_lib):
     if name == "treeline":
         _above_treeline(d)
     f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
+    if name.startswith("blowing"):
+        f[:, C["VIC_F_WIND"]] *= 3.5
     sd0, si0 = init_state.initial_state(d, f[0])
     if glacier:
         sd0[C["SD_GLAC_CUM_MASS_BALANCE"], d.hru_iparams[C["HPI_IS_GLACIER"]] != 0] = 0.0
