@@ -75,6 +75,8 @@ GPU_CASES = [
     ("frozen_fixed", dict(FROZEN, frozen_compat=0), "fixed", False, 12, 330),
     ("frozen_compat_glacier", dict(FROZEN, frozen_compat=1), "compat", True, 12, 100),
     ("wb_daily", dict(FULL_ENERGY=0, dt=24, snow_step=3), "plain", False, 10, 60),
+    # BLOWING: the binding hands veg_con's sigma_slope / lag_one / fetch to the device (HPD rows of ABI v3); strong wind
+    ("blowing_bands", dict(FULL_ENERGY=1, Nband=2, BLOWING=1), "plain", False, 24, 350),
 ]
 
 
@@ -87,6 +89,8 @@ def test_reference_runs_through_the_binding(case, oracle_lib, ref_available):
     opt = abi.default_options(**kw)
     d = domain.make_domain(40, opt, ntile=2, glacier_top_band=glacier)
     f, sf, dmy = domain.make_forcing(d, 0, nsteps, start_doy=doy)
+    if name.startswith("blowing"):
+        f[:, C["VIC_F_WIND"]] *= 3.5
     a, b = oracle_lib.RefModel(d, variant), oracle_lib.RefModel(d, variant)
     for m in (a, b):
         m.init_state(f[0], dmy[0], d.init_moist)
