@@ -1541,11 +1541,17 @@ static int fd_step(vicgpu_ctx* c, FdChunk* ch, KArgs ka) {
       if (c->o.IMPLICIT) {
         // the Newton iteration for every listed HRU; those it fails for go on the fall-back list, which the explicit kernel
         // (the same one, on that list) solves right after (func_surf_energy_bal.c:192-222)
-        CHKCH(ch, hipMemsetAsync(ch->d_fb_count, 0, sizeof(int) * NBUCKET, st));
+        CHKCH(ch, hipMemsetAsync(ch->d_fb_count, 0, sizeof(int) * (NBUCKET + 1), st));      // the fall-back segments and the work-list cursor
         IArgs ia;
         ia.ncell = c->ncell; ia.nhru = c->nhru; ia.Nband = c->o.Nband; ia.pimp = c->d_pimp; ia.hpi = c->d_hpi; ia.cell_params = c->d_cp;
-        ia.hkey = c->d_hkey; ia.fb_list = ch->d_fb_list; ia.fb_count = ch->d_fb_count; ia.lastexp = c->d_lastexp;
-        hipLaunchKernelGGL(vic_profile_solve_implicit, dim3((nmax + 63) / 64 > 0 ? (nmax + 63) / 64 : 1), dim3(64), 0, st, pa, ia);
+        ia.hkey = c->d_hkey; ia.fb_list = ch->d_fb_list; ia.fb_count = ch->d_fb_count; ia.lastexp = c->d_lastexp; ia.cursor = ch->d_fb_count + NBUCKET;
+        {
+          // persistent waves, a few per SIMD: a lane takes the next solve when its own ends (vic_implicit.hpp)
+          int nblk = (nmax + 63) / 64;
+          if (nblk > 4096) nblk = 4096;
+          if (nblk < 1) nblk = 1;
+          hipLaunchKernelGGL(vic_profile_solve_implicit, dim3(nblk), dim3(64), 0, st, pa, ia);
+        }
         CHKCH(ch, hipGetLastError());
         pa.list = ch->d_fb_list; pa.count = ch->d_fb_count;
       }
@@ -1923,7 +1929,7 @@ static int set_domain_impl(vicgpu_ctx* c, int ncell, int nhru, const double* cel
       HIPCHK(c, hipMalloc(&ch.d_elist[1], gb));
       if (c->o.IMPLICIT) {
         HIPCHK(c, hipMalloc(&ch.d_fb_list, gb * NBUCKET));
-        HIPCHK(c, hipMalloc(&ch.d_fb_count, sizeof(int) * NBUCKET));
+        HIPCHK(c, hipMalloc(&ch.d_fb_count, sizeof(int) * (NBUCKET + 1)));
       }
       HIPCHK(c, hipHostMalloc(&ch.h_count, sizeof(int) * CNT_TOTAL * RB_DEPTH, hipHostMallocDefault));
       if (ch.gcount) HIPCHK(c, copy_on(c->stream, ch.d_glist, gl.data(), sizeof(int) * ch.gcount, hipMemcpyHostToDevice));
